@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by importing the real WaveCap-SDR reference.
+
+Runs ONLY in the build container (needs /root/reference); the GPU box never sees
+the reference.  Output: small ``tests/golden/*.npz`` files holding recipe
+arguments (see ``tests/signals.py``), a sha256 of each generated input and the
+reference's outputs.  Usage:
+
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 python3 /root/repo/oracle/gen_golden.py [names...]
+
+Oracle semantics recorded in every fixture: numpy / scipy versions, numba absent
+(SURVEY.md F10).
+"""
+
+from __future__ import annotations
+
+import os
+import sys
+
+REF = "/root/reference/backend"
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+
+import numpy as np  # noqa: E402
+import scipy  # noqa: E402
+
+import signals as S  # noqa: E402
+
+import wavecapsdr.trunking  # noqa: E402,F401  (must precede capture: circular import)
+from wavecapsdr import capture as rc  # noqa: E402
+from wavecapsdr.dsp import fm as rfm  # noqa: E402
+from wavecapsdr.dsp.channelizer import PolyphaseChannelizer  # noqa: E402
+from wavecapsdr.dsp.fft.scipy_backend import ScipyFFTBackend  # noqa: E402
+from wavecapsdr.dsp.p25 import c4fm as rc4  # noqa: E402
+
+GOLD = os.path.join(REPO, "tests", "golden")
+META = dict(numpy=np.__version__, scipy=scipy.__version__, numba=bool(rc4.NUMBA_AVAILABLE))
+
+
+def save(name, **kw):
+    kw["meta"] = np.array(repr(META))
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **kw)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def gen_a1():
+    i16 = np.arange(-32768, 32768, dtype=np.int16)
+    # reference unpack rule cli.py:447-452
+    unpack = i16.astype(np.float32) / 32768.0
+    rng = np.random.default_rng(11)
+    edge = np.array([1.0, -1.0, 1.0 + 1e-7, -1.0 - 1e-7, 0.5, -0.5, 0.99999, -0.99999, 0.0, -0.0,
+                     1.5, -1.5, 3.0517578e-05, -3.0517578e-05, 1e-9, 0.999984], dtype=np.float32)
+    vals = np.concatenate([edge, rng.uniform(-1.2, 1.2, 8192 - edge.size).astype(np.float32)])
+    cin = (vals[0::2] + 1j * vals[1::2]).astype(np.complex64)
+    packed = np.frombuffer(rc.pack_iq16(cin.copy()), dtype=np.int16)
+    pcm = np.frombuffer(rc.pack_pcm16(vals.copy()), dtype=np.int16)
+    save("a1_int16", i16=i16, unpack_f32=unpack, pack_in=cin, pack_out=packed, pcm_in=vals, pcm_out=pcm)
+
+
+def gen_a2():
+    cases = [(120000, 25000, 2400000), (120000, -25000, 2400000), (120000, 1, 2400000),
+             (8192, 1199999, 2400000), (500000, 4900000, 10000000), (120000, -775000, 2400000)]
+    out = {}
+    for ci, (n, off, fs) in enumerate(cases):
+        iq = S.noise_c64(n, 200 + ci)
+        rc._get_freq_shift_exp.cache_clear()
+        y = rc.freq_shift(iq, float(off), fs)
+        rng = np.random.default_rng(300 + ci)
+        idx = np.unique(np.concatenate([np.arange(256), np.arange(n - 256, n),
+                                        rng.integers(0, n, 1024)])).astype(np.int64)
+        out[f"c{ci}_args"] = np.array([n, off, fs, 200 + ci], dtype=np.int64)
+        out[f"c{ci}_sha"] = np.array(S.sha256(iq))
+        out[f"c{ci}_idx"] = idx
+        out[f"c{ci}_y"] = y[idx]
+        out[f"c{ci}_tab"] = rc._get_freq_shift_exp(n, off, fs)[idx]
+    out["n_cases"] = np.array(len(cases))
+    save("a2_nco", **out)
+
+
+def gen_a3():
+    fs = 2400000
+    iq = S.fm_tone_c64(8192, fs, seed=31, audio_hz=1000.0, deviation=75000.0)
+    y = rfm.quadrature_demod(iq, fs)
+    iq2 = S.noise_c64(4096, 32)
+    y2 = rfm.quadrature_demod(iq2, 250000)
+    x = (np.random.default_rng(33).standard_normal(4096) * 0.7).astype(np.float32)
+    save("a3_quad", iq=iq, fs=np.array(fs), y=y, iq2=iq2, fs2=np.array(250000), y2=y2,
+         x=x, soft_clip=rfm.soft_clip(x), rms_norm=rfm.rms_normalize(x, target_rms=0.18))
+
+
+def gen_a6():
+    out = {}
+    cases = [(2400000, 48000, 120000, 61), (1000000, 48000, 20000, 62), (10000000, 48000, 50000, 63),
+             (2400000, 48000, 12345, 64), (250000, 48000, 8000, 65)]
+    for ci, (fi, fo, n, seed) in enumerate(cases):
+        x = (np.random.default_rng(seed).standard_normal(n) * 0.3).astype(np.float32)
+        y = rfm.resample_poly(x, fi, fo)
+        out[f"c{ci}_args"] = np.array([fi, fo, n, seed], dtype=np.int64)
+        out[f"c{ci}_sha"] = np.array(S.sha256(x))
+        out[f"c{ci}_y"] = y
+    out["n_cases"] = np.array(len(cases))
+    save("a6_resample", **out)
+
+
+def _cfg(mode, off):
+    cfg = rc.ChannelConfig(id="g", capture_id="c", mode=mode, offset_hz=float(off))
+    if mode == "nbfm":  # mode defaults, capture.py:3444-3452
+        cfg.enable_deemphasis = False
+        cfg.enable_mpx_filter = False
+        cfg.enable_fm_highpass = False
+        cfg.enable_fm_lowpass = False
+    return cfg
+
+
+def gen_chain():
+    out = {}
+    fs = 2400000
+    n = 120000
+    # NBFM: config-2 content, two consecutive chunks, three channel offsets
+    offs = S.nbfm_bank_offsets()
+    k_list = [0, 13, 31]
+    for chunk in range(2):
+        iq = S.nbfm_bank_c64(n, fs, seed=500 + chunk, start=chunk * n)
+        i16 = S.pack_iq16_np(iq)
+        iq_q = i16.astype(np.float32) / 32768.0
+        iq_q = (iq_q[0::2] + 1j * iq_q[1::2]).astype(np.complex64)
+        out[f"nbfm{chunk}_sha_i16"] = np.array(S.sha256(i16))
+        for k in k_list:
+            rc._get_freq_shift_exp.cache_clear()
+            audio, met = rc._process_channel_dsp_stateless(iq_q, fs, _cfg("nbfm", offs[k]))
+            out[f"nbfm{chunk}_k{k}_audio"] = audio
+            out[f"nbfm{chunk}_k{k}_met"] = np.array([met["rssi_db"], met["signal_power_db"]])
+    out["nbfm_k"] = np.array(k_list)
+    out["nbfm_args"] = np.array([fs, n, 500], dtype=np.int64)
+    # WBFM: config-1 content, defaults (de-emphasis 75us + MPX 15 kHz), offset 0 and +200 kHz
+    for ci, off in enumerate([0.0, 200000.0]):
+        iq = S.fm_tone_c64(n, fs, seed=510 + ci, carrier_hz=off)
+        cfg = rc.ChannelConfig(id="w", capture_id="c", mode="wbfm", offset_hz=off)
+        rc._get_freq_shift_exp.cache_clear()
+        audio, met = rc._process_channel_dsp_stateless(iq, fs, cfg)
+        out[f"wbfm{ci}_sha"] = np.array(S.sha256(iq))
+        out[f"wbfm{ci}_audio"] = audio
+        out[f"wbfm{ci}_met"] = np.array([met["rssi_db"], met["signal_power_db"]])
+        out[f"wbfm{ci}_args"] = np.array([fs, n, 510 + ci, int(off)], dtype=np.int64)
+    # AM / SSB defaults at 250 kS/s (shorter: IIR + AGC stages)
+    fs2, n2 = 96000, 9600
+    iq = S.am_tone_c64(n2, fs2, seed=520, carrier_hz=10000.0)
+    cfg = rc.ChannelConfig(id="a", capture_id="c", mode="am", offset_hz=10000.0, enable_agc=True)
+    audio, met = rc._process_channel_dsp_stateless(iq, fs2, cfg)
+    out["am_sha"] = np.array(S.sha256(iq))
+    assert audio is not None
+    out["am_audio"] = audio
+    out["am_met"] = np.array([met["rssi_db"], met["signal_power_db"]])
+    out["am_args"] = np.array([fs2, n2, 520, 10000], dtype=np.int64)
+    for mi, mode in enumerate(["usb", "lsb"]):
+        iq = S.am_tone_c64(n2, fs2, seed=530 + mi, carrier_hz=-5000.0, depth=0.9)
+        cfg = rc.ChannelConfig(id="s", capture_id="c", mode="ssb", offset_hz=-5000.0, enable_agc=True,
+                               ssb_mode=mode)
+        audio, met = rc._process_channel_dsp_stateless(iq, fs2, cfg)
+        out[f"ssb{mi}_sha"] = np.array(S.sha256(iq))
+        assert audio is not None
+        out[f"ssb{mi}_audio"] = audio
+        out[f"ssb{mi}_met"] = np.array([met["rssi_db"], met["signal_power_db"]])
+    out["ssb_args"] = np.array([fs2, n2, 530, -5000], dtype=np.int64)
+    save("chain_analog", **out)
+
+
+def gen_a7():
+    out = {}
+    cases = [(1_000_000, 25000, 40, 701), (8_000_000, 25000, 320, 702), (10_000_000, 9765, 1024, 703)]
+    for ci, (fs, bw, M, seed) in enumerate(cases):
+        ch = PolyphaseChannelizer(fs, bw)
+        assert ch.channel_count == M
+        n1 = M * 12 + M // 2 + 37      # not a multiple of the hop: trailing samples dropped
+        n2 = M * 7 + 5
+        x = S.noise_c64(n1 + n2, seed)
+        r1 = np.array(ch.process(x[:n1]))
+        r2 = np.array(ch.process(x[n1:]))
+        out[f"c{ci}_args"] = np.array([fs, bw, M, seed, n1, n2], dtype=np.int64)
+        out[f"c{ci}_sha"] = np.array(S.sha256(x))
+        out[f"c{ci}_r1"] = r1.astype(np.complex64)
+        out[f"c{ci}_r2"] = r2.astype(np.complex64)
+        out[f"c{ci}_hist"] = ch.arm_history.copy()
+        if ci == 0:
+            out["c0_arms"] = ch.arms.copy()
+        out[f"c{ci}_arms_sha"] = np.array(S.sha256(ch.arms))
+        out[f"c{ci}_ex5"] = ch.extract_channel(list(r1), 5)
+    # short input (< M) returns no hops
+    ch = PolyphaseChannelizer(1_000_000, 25000)
+    out["short_len"] = np.array(len(ch.process(S.noise_c64(39, 1))))
+    out["n_cases"] = np.array(len(cases))
+    save("a7_pfb", **out)
+
+
+def gen_a8():
+    out = {}
+    fs = 2400000
+    for ci, N in enumerate([512, 1024, 2048, 4096]):
+        iq = S.fm_tone_c64(N + 100, fs, seed=800 + ci, deviation=20000.0, carrier_hz=123456.0, noise_amp=0.01)
+        r = ScipyFFTBackend(N).execute(iq, fs)
+        out[f"c{ci}_args"] = np.array([N, fs, 800 + ci], dtype=np.int64)
+        out[f"c{ci}_sha"] = np.array(S.sha256(iq))
+        out[f"c{ci}_power"] = r.power_db
+        out[f"c{ci}_freqs"] = r.freqs
+        out[f"c{ci}_bin"] = np.array(r.bin_hz)
+    r = ScipyFFTBackend(1024).execute(S.noise_c64(100, 1), fs)
+    out["short_power"] = r.power_db
+    out["n_cases"] = np.array(4)
+    save("a8_spectrum", **out)
+
+
+def gen_c4fm():
+    """A9-A11: full C4FMDemodulator.demodulate on streamed calls."""
+    out = {}
+    cases = [
+        # (fs, n_total, call_len, seed, snr_db, foff_hz, silence)
+        (48000, 48000 * 3, 4800, 1000, 20.0, 120.0, None),
+        (48000, 48000 * 2, 4800, 1001, 8.0, -300.0, None),
+        (50000, 50000 * 2, 5000, 1002, 30.0, 250.0, None),
+        (19200, 19200 * 3, 1920, 1003, 15.0, -80.0, None),
+        (48000, 48000 * 4, 4800, 1004, 20.0, 0.0, (60000, 110000)),   # fine-sync loss + buffer shifts
+        (48000, 48000 * 1, 4800, 1005, -30.0, 0.0, None),             # essentially noise
+        (48000, 48000 * 2, 7777, 1006, 25.0, 390.0, None),            # ragged call length
+    ]
+    for ci, (fs, n, call, seed, snr, foff, sil) in enumerate(cases):
+        iq, _ = S.c4fm_iq(n, fs, seed, snr_db=snr, freq_offset_hz=foff, silence=sil)
+        d = rc4.C4FMDemodulator(sample_rate=fs)
+        dib, soft, counts = [], [], []
+        for s in range(0, n, call):
+            a, b = d.demodulate(iq[s:s + call])
+            dib.append(a)
+            soft.append(b)
+            counts.append(len(a))
+        out[f"c{ci}_args"] = np.array([fs, n, call, seed, int(round(snr * 10)), int(round(foff * 10)),
+                                       -1 if sil is None else sil[0], -1 if sil is None else sil[1]],
+                                      dtype=np.int64)
+        out[f"c{ci}_sha"] = np.array(S.sha256(iq))
+        out[f"c{ci}_dibits"] = np.concatenate(dib).astype(np.uint8)
+        out[f"c{ci}_soft"] = np.concatenate(soft).astype(np.float32)
+        out[f"c{ci}_counts"] = np.array(counts, dtype=np.int32)
+        out[f"c{ci}_state"] = np.array([d._sync_count, int(d._fine_sync), d._equalizer.pll,
+                                        d._equalizer.gain, float(d._sample_point)])
+        print(f"  c4fm case {ci}: syms={sum(counts)} syncs={d._sync_count} fine={d._fine_sync} "
+              f"pll={d._equalizer.pll:.4f} gain={d._equalizer.gain:.4f}")
+    out["n_cases"] = np.array(len(cases))
+    # filter designs (host-side, but pinned so the product's taps are the reference's taps)
+    for fs in (48000, 50000, 19200):
+        d = rc4.C4FMDemodulator(sample_rate=fs)
+        out[f"lpf_{fs}"] = d._baseband_lpf
+        out[f"rrc_{fs}"] = d._rrc_filter
+    out["interp_taps"] = rc4._interpolator.TAPS.copy()
+    save("c4fm", **out)
+
+
+ALL = dict(a1=gen_a1, a2=gen_a2, a3=gen_a3, a6=gen_a6, chain=gen_chain, a7=gen_a7, a8=gen_a8, c4fm=gen_c4fm)
+
+if __name__ == "__main__":
+    import logging
+    logging.disable(logging.CRITICAL)
+    names = sys.argv[1:] or list(ALL)
+    for nm in names:
+        ALL[nm]()

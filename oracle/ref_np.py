@@ -1,0 +1,410 @@
+"""CPU oracle (numpy) for the WaveCap-SDR per-channel DSP hot path.
+
+TEST INFRASTRUCTURE ONLY.  This module is a CPU restatement of the reference's
+algorithm, written from its published behaviour; it is imported only by
+``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` -- never by the product package (``wavecap-sdr_amd/wavehip``), which
+fails loudly when the HIP library is missing.
+
+Parity pin: every function below is checked against golden vectors produced by
+importing the real reference in the build container (``oracle/gen_golden.py``
+-> ``tests/golden/*.npz``, test ``tests/test_oracle_golden.py``).  The reference
+itself holds no numeric golden vectors for this path, so those
+generated fixtures are the pin.
+
+All ``file:line`` citations are relative to the reference checkout
+(``backend/wavecapsdr/...``).  Third-party arithmetic the reference delegates to
+(scipy 1.15.3 ``resample_poly``/``upfirdn``/``lfilter``/``firwin``, numpy 2.2.6
+``fft``) is restated from the published algorithm; filter *design* helpers
+(``firwin``, ``butter``, ``remez``) are called from scipy because the product's
+host code calls the very same functions and they are not on the per-sample path.
+"""
+
+from __future__ import annotations
+
+from math import gcd
+
+import numpy as np
+from scipy import signal as _sig
+
+# --------------------------------------------------------------------------
+# A1  int16 IQ wire conventions
+# --------------------------------------------------------------------------
+
+
+def pack_iq16(samples: np.ndarray) -> np.ndarray:
+    """capture.py:102-116 -- clip(-1,1) * 32767.0 -> astype(int16) (truncate toward 0).
+
+    Returns the interleaved int16 array (the reference returns its bytes)."""
+    f = np.ascontiguousarray(samples.astype(np.complex64)).view(np.float32).copy()
+    np.clip(f, -1.0, 1.0, out=f)
+    return (f * np.float32(32767.0)).astype(np.int16)
+
+
+def unpack_iq16(i16: np.ndarray) -> np.ndarray:
+    """cli.py:447-452 / harness.py:274 -- int16.astype(f32)/32768.0, I,Q interleaved."""
+    f = i16.astype(np.float32) / np.float32(32768.0)
+    return (f[0::2] + 1j * f[1::2]).astype(np.complex64)
+
+
+def pack_pcm16(x: np.ndarray) -> np.ndarray:
+    """capture.py:119-131."""
+    f = np.ascontiguousarray(x, dtype=np.float32).copy()
+    np.clip(f, -1.0, 1.0, out=f)
+    f *= np.float32(32767.0)
+    return f.astype(np.int16)
+
+
+# --------------------------------------------------------------------------
+# A2  stateless NCO (float32 phase product)
+# --------------------------------------------------------------------------
+
+
+def nco_table(n: int, offset_hz: int, sample_rate: int) -> np.ndarray:
+    """capture.py:166-177.  The Python complex scalar is weak, so the product with the
+    float32 ramp happens in complex64: phase[n] = f32(c) * f32(n) rounded to float32,
+    then cos/sin of that float32 value."""
+    c = np.float32(-2.0 * np.pi * (offset_hz / float(sample_rate)))
+    ph32 = c * np.arange(n, dtype=np.float32)  # float32 product, one rounding
+    ph = ph32.astype(np.float64)
+    return (np.cos(ph) + 1j * np.sin(ph)).astype(np.complex64)
+
+
+def freq_shift(iq: np.ndarray, offset_hz: float, sample_rate: int) -> np.ndarray:
+    """capture.py:180-193 (phase restarts at n=0 every call; offset rounded to int)."""
+    if offset_hz == 0.0 or iq.size == 0:
+        return iq
+    ph = nco_table(iq.shape[0], round(offset_hz), sample_rate)
+    return (iq.astype(np.complex64, copy=False) * ph).astype(np.complex64)
+
+
+def freq_shift_am(iq: np.ndarray, offset_hz: float, sample_rate: int) -> np.ndarray:
+    """dsp/am.py:23-42 -- float64 phase, *positive* sign (used for the SSB BFO)."""
+    if offset_hz == 0.0 or iq.size == 0:
+        return iq
+    n = np.arange(iq.shape[0], dtype=np.float64)
+    ph = np.exp(1j * 2.0 * np.pi * (offset_hz / float(sample_rate)) * n).astype(np.complex64)
+    return (iq.astype(np.complex64, copy=False) * ph).astype(np.complex64)
+
+
+# --------------------------------------------------------------------------
+# A3  FM discriminator, RMS normalise, soft clip
+# --------------------------------------------------------------------------
+
+
+def quadrature_demod(iq: np.ndarray, sample_rate: int) -> np.ndarray:
+    """dsp/fm.py:65-97 -- out[0]=0, out[n]=atan2f(x[n] conj x[n-1]) * f32(fs/(2 pi 75000))."""
+    if iq.size == 0:
+        return np.empty(0, dtype=np.float32)
+    x = iq.astype(np.complex64, copy=False)
+    prod = x[1:] * np.conj(x[:-1])
+    out = np.empty(iq.size, dtype=np.float32)
+    out[0] = 0.0
+    out[1:] = np.arctan2(prod.imag, prod.real) * np.float32(sample_rate / (2.0 * np.pi * 75000.0))
+    return out
+
+
+def rms_normalize(x: np.ndarray, target_rms: float = 0.18, min_rms: float = 1e-4) -> np.ndarray:
+    """dsp/fm.py:42-62."""
+    if x.size == 0:
+        return x
+    rms = float(np.sqrt(np.mean(x ** 2)))
+    if rms > min_rms:
+        return x * (target_rms / rms)
+    return x
+
+
+def soft_clip_fm(x: np.ndarray) -> np.ndarray:
+    """dsp/fm.py:26-39 -- tanh(1.5 x)/tanh(1.5) * 0.95 in float32."""
+    k = np.float32(1.5)
+    norm = np.float32(1.0 / np.tanh(1.5))
+    head = np.float32(0.95)
+    return np.tanh(x * k) * norm * head
+
+
+def soft_clip_agc(x: np.ndarray) -> np.ndarray:
+    """dsp/agc.py:58-70 -- same knee without the 0.95 headroom."""
+    return np.tanh(x * np.float32(1.5)) * np.float32(1.0 / np.tanh(1.5))
+
+
+# --------------------------------------------------------------------------
+# A6  polyphase rational resampler (scipy.signal.resample_poly restated)
+# --------------------------------------------------------------------------
+
+
+def resample_design(in_rate: int, out_rate: int) -> tuple[np.ndarray, int, int, int]:
+    """Taps and alignment of ``scipy.signal.resample_poly`` (scipy 1.15.3
+    ``_signaltools.resample_poly``): returns (h float64 already scaled by ``up``, up,
+    down, d0) such that  y[m] = sum_j h[j] * xup[m*down + d0 - j]  where ``xup`` is the
+    zero-stuffed input (xup[i*up] = x[i])."""
+    g = gcd(int(in_rate), int(out_rate))
+    up = int(out_rate) // g
+    down = int(in_rate) // g
+    max_rate = max(up, down)
+    half_len = 10 * max_rate
+    h = _sig.firwin(2 * half_len + 1, 1.0 / max_rate, window=("kaiser", 5.0)).astype(np.float64)
+    h = h * up
+    n_pre_pad = down - half_len % down
+    n_pre_remove = (half_len + n_pre_pad) // down
+    d0 = n_pre_remove * down - n_pre_pad
+    return h, up, down, d0
+
+
+def resample_out_len(n_in: int, up: int, down: int) -> int:
+    n_out = n_in * up
+    return n_out // down + (1 if n_out % down else 0)
+
+
+def resample_poly(x: np.ndarray, in_rate: int, out_rate: int) -> np.ndarray:
+    """dsp/fm.py:184-221 -> scipy.signal.resample_poly(x.astype(f64), up, down).astype(f32).
+
+    Restated as a direct zero-padded FIR evaluated only at the kept outputs."""
+    if x.size == 0 or in_rate == out_rate:
+        return x.astype(np.float32, copy=False)
+    h, up, down, d0 = resample_design(in_rate, out_rate)
+    n_in = x.shape[0]
+    n_out = resample_out_len(n_in, up, down)
+    nt = h.shape[0]
+    xup = np.zeros(n_in * up, dtype=np.float64)
+    xup[::up] = x.astype(np.float64)
+    # window for output m covers xup[m*down + d0 - (nt-1) .. m*down + d0]
+    lo_pad = nt - 1
+    hi_pad = max(0, (n_out - 1) * down + d0 + 1 - xup.shape[0])
+    xp = np.concatenate([np.zeros(lo_pad), xup, np.zeros(hi_pad)])
+    starts = np.arange(n_out) * down + d0  # index of newest sample, in xup coordinates
+    win = np.lib.stride_tricks.sliding_window_view(xp, nt)[starts]  # win[m, i] = xup[m*down+d0-(nt-1)+i]
+    y = win @ h[::-1]
+    return y.astype(np.float32)
+
+
+# --------------------------------------------------------------------------
+# IIR helpers (A14): cached Butterworth / de-emphasis, applied with lfilter
+# --------------------------------------------------------------------------
+
+
+def lfilter_df2t(b: np.ndarray, a: np.ndarray, x: np.ndarray, dtype=np.float64) -> np.ndarray:
+    """Direct-form-II-transposed recurrence of ``scipy.signal.lfilter`` (zero initial
+    state) in ``dtype`` -- pure-Python loop, for short cross-checks only."""
+    b = np.asarray(b, dtype=dtype)
+    a = np.asarray(a, dtype=dtype)
+    b = b / a[0]
+    a = a / a[0]
+    n = max(len(a), len(b))
+    bb = np.zeros(n, dtype=dtype)
+    aa = np.zeros(n, dtype=dtype)
+    bb[: len(b)] = b
+    aa[: len(a)] = a
+    z = np.zeros(n, dtype=dtype)
+    y = np.empty(len(x), dtype=dtype)
+    for i, xi in enumerate(np.asarray(x, dtype=dtype)):
+        yi = z[0] + bb[0] * xi
+        for k in range(1, n):
+            z[k - 1] = (z[k] if k < n - 1 else dtype(0)) + bb[k] * xi - aa[k] * yi
+        y[i] = yi
+    return y
+
+
+def deemphasis_coeffs(sample_rate: int, tau: float) -> tuple[np.ndarray, np.ndarray]:
+    """dsp/fm.py:101-108."""
+    tau_us = int(tau * 1e6)
+    t = tau_us * 1e-6
+    alpha = 1.0 / (1.0 + (1.0 / (2.0 * np.pi * t * sample_rate)))
+    return np.array([alpha], dtype=np.float32), np.array([1.0, -(1.0 - alpha)], dtype=np.float32)
+
+
+def deemphasis_filter(x: np.ndarray, sample_rate: int, tau: float = 75e-6) -> np.ndarray:
+    """dsp/fm.py:111-126 (float32 one-pole)."""
+    b, a = deemphasis_coeffs(sample_rate, tau)
+    return _sig.lfilter(b, a, x).astype(np.float32)
+
+
+def lpf_audio(x: np.ndarray, sample_rate: int, cutoff: float = 15_000) -> np.ndarray:
+    """dsp/fm.py:129-181 -- butter(5, cutoff) applied in float64, zero state per chunk."""
+    nc = int(cutoff) / (sample_rate / 2.0)
+    if nc >= 1.0 or x.size == 0:
+        return x.astype(np.float32, copy=False)
+    b, a = _sig.butter(5, nc, btype="low")
+    return _sig.lfilter(b, a, x).astype(np.float32)
+
+
+def butter_filter(x: np.ndarray, sample_rate: int, kind: str, cutoff, order: int = 5) -> np.ndarray:
+    """dsp/filters.py:86-221 -- highpass/lowpass/bandpass Butterworth order 5 via lfilter."""
+    nyq = sample_rate / 2.0
+    if kind == "band":
+        lo, hi = cutoff
+        wn = [lo / nyq, hi / nyq]
+        if wn[0] <= 0 or wn[1] >= 1.0:
+            return x.astype(np.float32, copy=False)
+        b, a = _sig.butter(order, wn, btype="band")
+    else:
+        wn = cutoff / nyq
+        if wn >= 1.0 or wn <= 0:
+            return x.astype(np.float32, copy=False)
+        b, a = _sig.butter(order, wn, btype=kind)
+    return _sig.lfilter(b, a, x).astype(np.float32)
+
+
+# --------------------------------------------------------------------------
+# Chains on the dispatcher (capture.py:298-439 with mode defaults capture.py:3425-3496)
+# --------------------------------------------------------------------------
+
+
+def nbfm_demod(iq: np.ndarray, sample_rate: int, audio_rate: int = 48_000) -> np.ndarray:
+    """dsp/fm.py:317-406 with every optional filter off (the NBFM mode default)."""
+    fm = quadrature_demod(iq, sample_rate)
+    fm = rms_normalize(fm, target_rms=0.18)
+    audio = resample_poly(fm, sample_rate, audio_rate)
+    return soft_clip_fm(audio)
+
+
+def wbfm_demod(iq: np.ndarray, sample_rate: int, audio_rate: int = 48_000,
+               deemphasis_tau: float = 75e-6, mpx_cutoff_hz: float = 15_000) -> np.ndarray:
+    """dsp/fm.py:228-314 with the WBFM mode defaults (de-emphasis 75 us + MPX 15 kHz)."""
+    fm = quadrature_demod(iq, sample_rate)
+    fm = deemphasis_filter(fm, sample_rate, tau=deemphasis_tau)
+    fm = lpf_audio(fm, sample_rate, cutoff=mpx_cutoff_hz)
+    fm = rms_normalize(fm, target_rms=0.18)
+    audio = resample_poly(fm, sample_rate, audio_rate)
+    return soft_clip_fm(audio)
+
+
+def channel_metrics_db(x: np.ndarray) -> float:
+    """capture.py:331-334 / 436-437 -- 10 log10(mean(|x|^2) + 1e-10)."""
+    if np.iscomplexobj(x):
+        p = np.mean(np.abs(x) ** 2)
+    else:
+        p = np.mean(x ** 2)
+    return float(10.0 * np.log10(p + 1e-10))
+
+
+def process_channel_nbfm(samples: np.ndarray, sample_rate: int, offset_hz: float,
+                         audio_rate: int = 48_000):
+    """capture.py:298-439 for mode 'nbfm' -> (audio, {'rssi_db', 'signal_power_db'})."""
+    metrics = {}
+    if samples.size == 0:
+        return None, metrics
+    if not np.isfinite(samples).all():
+        return None, metrics
+    base = samples if offset_hz == 0.0 else freq_shift(samples, offset_hz, sample_rate)
+    metrics["rssi_db"] = channel_metrics_db(base)
+    audio = nbfm_demod(base, sample_rate, audio_rate)
+    if not np.isfinite(audio).all() or float(np.max(np.abs(audio))) > 1.2:
+        return None, metrics
+    metrics["signal_power_db"] = channel_metrics_db(audio)
+    return audio, metrics
+
+
+def process_channel_wbfm(samples: np.ndarray, sample_rate: int, offset_hz: float,
+                         audio_rate: int = 48_000):
+    metrics = {}
+    if samples.size == 0 or not np.isfinite(samples).all():
+        return None, metrics
+    base = samples if offset_hz == 0.0 else freq_shift(samples, offset_hz, sample_rate)
+    metrics["rssi_db"] = channel_metrics_db(base)
+    audio = wbfm_demod(base, sample_rate, audio_rate)
+    if not np.isfinite(audio).all() or float(np.max(np.abs(audio))) > 1.2:
+        return None, metrics
+    metrics["signal_power_db"] = channel_metrics_db(audio)
+    return audio, metrics
+
+
+# --------------------------------------------------------------------------
+# A7  2x-oversampled polyphase filterbank
+# --------------------------------------------------------------------------
+
+
+class PolyphaseChannelizer:
+    """dsp/channelizer.py:28-158, vectorised over hops.
+
+    Quirks kept: hop M/2 but the whole M-block is inserted into column 0
+    of the arm history; no per-hop circular shift; taps not reversed per arm; forward
+    unnormalised FFT; trailing <M samples dropped; only ``arm_history`` carries over."""
+
+    def __init__(self, sample_rate: float, channel_bandwidth: int = 25000, taps_per_channel: int = 9):
+        self.sample_rate = sample_rate
+        self.channel_bandwidth = channel_bandwidth
+        self.taps_per_channel = taps_per_channel
+        self.channel_count = int(sample_rate / channel_bandwidth)
+        if self.channel_count % 2 != 0:
+            self.channel_count -= 1
+        self.channel_sample_rate = (sample_rate / self.channel_count) * 2
+        self.arms = design_pfb_arms(sample_rate, channel_bandwidth, taps_per_channel, self.channel_count)
+        self.arm_history = np.zeros((self.channel_count, taps_per_channel), dtype=np.complex64)
+
+    def reset(self) -> None:
+        self.arm_history.fill(0)
+
+    def process(self, samples: np.ndarray) -> np.ndarray:
+        """Returns c64[hops, M] (row h == the reference's results[h])."""
+        M, T = self.channel_count, self.taps_per_channel
+        hop = M // 2
+        n = len(samples)
+        H = 0 if n < M else (n - M) // hop + 1
+        if H == 0:
+            return np.zeros((0, M), dtype=np.complex64)
+        x = np.ascontiguousarray(samples, dtype=np.complex64)
+        blocks = np.lib.stride_tricks.as_strided(x, shape=(H, M), strides=(hop * x.itemsize, x.itemsize))
+        # B[r] = block_{r-(T-1)}; rows 0..T-2 come from the carried history (column j = block_{-1-j}),
+        # column T-1 of the history is about to be rolled out and never used.
+        B = np.empty((H + T - 1, M), dtype=np.complex64)
+        for j in range(T - 1):
+            B[T - 2 - j] = self.arm_history[:, j]
+        B[T - 1:] = blocks
+        acc = np.zeros((H, M), dtype=np.complex128)
+        for j in range(T):
+            acc += B[T - 1 - j: T - 1 - j + H].astype(np.complex128) * self.arms[:, j][None, :]
+        y = acc.astype(np.complex64)
+        out = np.fft.fft(y, axis=1).astype(np.complex64)
+        # new history: column j = block_{H-1-j}
+        for j in range(T):
+            self.arm_history[:, j] = B[H + T - 2 - j]
+        return out
+
+    @staticmethod
+    def extract_channel(results: np.ndarray, idx: int) -> np.ndarray:
+        return np.asarray(results)[:, idx].astype(np.complex64)
+
+
+def design_pfb_arms(sample_rate: float, channel_bandwidth: int, taps_per_channel: int, M: int) -> np.ndarray:
+    """dsp/channelizer.py:69-89."""
+    L = M * taps_per_channel - 1
+    cutoff = (channel_bandwidth * 0.9) / (sample_rate / 2)
+    proto = _sig.firwin(L, cutoff, window=("kaiser", 8.0)).astype(np.float64)
+    arms = np.zeros((M, taps_per_channel), dtype=np.float64)
+    for k in range(M):
+        t = proto[k::M]
+        arms[k, : len(t)] = t
+    return arms
+
+
+# --------------------------------------------------------------------------
+# A8  spectrum
+# --------------------------------------------------------------------------
+
+
+def spectrum(iq: np.ndarray, sample_rate: int, fft_size: int):
+    """dsp/fft/scipy_backend.py:38-79 -> (power_db f32[N], freqs f32[N], bin_hz)."""
+    N = fft_size
+    if iq.size < N:
+        return np.zeros(N, np.float32), np.zeros(N, np.float32), sample_rate / N
+    from scipy import fft as _sfft  # the reference's backend is scipy.fft (pocketfft C++)
+
+    w = np.hanning(N).astype(np.float32)
+    X = _sfft.fftshift(_sfft.fft(iq[:N] * w))
+    p = 20.0 * np.log10(np.abs(X) + 1e-10)
+    freqs = _sfft.fftshift(_sfft.fftfreq(N, 1.0 / sample_rate))
+    return p.astype(np.float32), freqs.astype(np.float32), sample_rate / N
+
+
+# --------------------------------------------------------------------------
+# A13  activity statistics (per-channel power of a PFB output block)
+# --------------------------------------------------------------------------
+
+
+def pfb_channel_stats(out: np.ndarray) -> np.ndarray:
+    """Per-channel {sum p, sum p^2, count, min p, max p} of p=|y|^2 over hops, the
+    BinStats fields of channel_classifier.py:17-48 applied to filterbank channels.
+    Returns float64[M, 5]."""
+    p = (out.real.astype(np.float64) ** 2 + out.imag.astype(np.float64) ** 2)
+    H = p.shape[0]
+    return np.stack([p.sum(0), (p * p).sum(0), np.full(p.shape[1], float(H)), p.min(0), p.max(0)], axis=1)

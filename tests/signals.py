@@ -1,0 +1,166 @@
+"""Seeded synthetic signal factories shared by the golden generator, the parity
+tests and bench.py.
+
+Every factory is a pure function of its arguments (numpy ``default_rng`` with an
+explicit seed), so a fixture only has to store the recipe arguments, a sha256 of
+the generated input and the expected output.  Recipes follow the reference's
+own test factories (reference ``backend/tests/conftest.py:22-88``) and the
+configs of BASELINE.json / SURVEY.md §8(d).
+"""
+
+from __future__ import annotations
+
+import hashlib
+
+import numpy as np
+
+P25_SYNC_DIBITS = None  # filled below
+
+
+def sha256(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def noise_c64(n: int, seed: int, amp: float = 0.5) -> np.ndarray:
+    """``amp*(randn + j randn)`` as complex64 (benchmark_dsp.py:119 recipe, seeded)."""
+    rng = np.random.default_rng(seed)
+    re = rng.standard_normal(n, dtype=np.float32)
+    im = rng.standard_normal(n, dtype=np.float32)
+    return ((re + 1j * im) * np.float32(amp)).astype(np.complex64)
+
+
+def fm_tone_c64(
+    n: int,
+    fs: float,
+    seed: int,
+    audio_hz: float = 1000.0,
+    deviation: float = 75_000.0,
+    carrier_hz: float = 0.0,
+    noise_amp: float = 0.05,
+    amp: float = 0.7,
+) -> np.ndarray:
+    """FM-modulated tone at ``carrier_hz`` plus complex noise (conftest.py:42-56 recipe)."""
+    t = np.arange(n, dtype=np.float64) / fs
+    phase = (deviation / audio_hz) * np.sin(2 * np.pi * audio_hz * t) + 2 * np.pi * carrier_hz * t
+    iq = amp * np.exp(1j * phase)
+    rng = np.random.default_rng(seed)
+    iq = iq + noise_amp * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    return iq.astype(np.complex64)
+
+
+def am_tone_c64(n: int, fs: float, seed: int, audio_hz: float = 800.0, depth: float = 0.6,
+                carrier_hz: float = 0.0, noise_amp: float = 0.02, amp: float = 0.5) -> np.ndarray:
+    t = np.arange(n, dtype=np.float64) / fs
+    env = amp * (1.0 + depth * np.sin(2 * np.pi * audio_hz * t))
+    iq = env * np.exp(2j * np.pi * carrier_hz * t)
+    rng = np.random.default_rng(seed)
+    iq = iq + noise_amp * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    return iq.astype(np.complex64)
+
+
+def nbfm_bank_c64(n: int, fs: float, seed: int, n_ch: int = 32, spacing: float = 50_000.0,
+                  deviation: float = 5_000.0, noise_amp: float = 0.01, start: int = 0) -> np.ndarray:
+    """Config 2 content: ``n_ch`` NBFM carriers at offsets ``(k-(n_ch-1)/2)*spacing``
+    with distinct 300..3000 Hz tones, plus noise."""
+    t = (np.arange(n, dtype=np.float64) + start) / fs
+    x = np.zeros(n, dtype=np.complex128)
+    for k in range(n_ch):
+        off = (k - (n_ch - 1) / 2.0) * spacing
+        tone = 300.0 + (2700.0 * k) / max(1, n_ch - 1)
+        ph = 2 * np.pi * off * t + (deviation / tone) * np.sin(2 * np.pi * tone * t)
+        x += (0.6 / n_ch) * np.exp(1j * ph)
+    rng = np.random.default_rng(seed)
+    x += noise_amp * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    return x.astype(np.complex64)
+
+
+def nbfm_bank_offsets(n_ch: int = 32, spacing: float = 50_000.0) -> list[float]:
+    return [float((k - (n_ch - 1) / 2.0) * spacing) for k in range(n_ch)]
+
+
+def pack_iq16_np(x: np.ndarray) -> np.ndarray:
+    """Reference wire rule (capture.py:102-116): clip(-1,1)*32767 -> astype(int16)."""
+    f = np.ascontiguousarray(x.astype(np.complex64)).view(np.float32).copy()
+    np.clip(f, -1.0, 1.0, out=f)
+    return (f * np.float32(32767.0)).astype(np.int16)
+
+
+# --------------------------------------------------------------------------
+# P25 C4FM synthetic transmitter
+# --------------------------------------------------------------------------
+
+def p25_sync_dibits() -> np.ndarray:
+    """24 dibits of the frame sync 0x5575F5FF77FF (c4fm.py:2277-2299)."""
+    pattern = 0x5575F5FF77FF
+    return np.array([(pattern >> ((23 - i) * 2)) & 3 for i in range(24)], dtype=np.uint8)
+
+
+_DIBIT_TO_SYMBOL = np.array([1.0, 3.0, -1.0, -3.0])  # dibit 0:+1 1:+3 2:-1 3:-3 (c4fm.py:6-11)
+
+
+def _rrc_pulse(t: np.ndarray, alpha: float) -> np.ndarray:
+    """Root-raised-cosine impulse response at times ``t`` (in symbols)."""
+    out = np.empty_like(t)
+    eps = 1e-9
+    z = np.abs(t) < eps
+    s = np.abs(np.abs(t) - 1.0 / (4 * alpha)) < eps
+    r = ~(z | s)
+    out[z] = 1 - alpha + 4 * alpha / np.pi
+    out[s] = (alpha / np.sqrt(2)) * ((1 + 2 / np.pi) * np.sin(np.pi / (4 * alpha))
+                                     + (1 - 2 / np.pi) * np.cos(np.pi / (4 * alpha)))
+    tr = t[r]
+    out[r] = (np.sin(np.pi * tr * (1 - alpha)) + 4 * alpha * tr * np.cos(np.pi * tr * (1 + alpha))) / (
+        np.pi * tr * (1 - (4 * alpha * tr) ** 2))
+    return out
+
+
+def c4fm_frames_dibits(n_symbols: int, seed: int, frame_len: int = 360) -> np.ndarray:
+    """Repeating TSDU-like frames: 24-dibit sync + random dibits (config 4)."""
+    rng = np.random.default_rng(seed)
+    d = rng.integers(0, 4, size=n_symbols, dtype=np.uint8)
+    sync = p25_sync_dibits()
+    for s in range(0, n_symbols - 24, frame_len):
+        d[s:s + 24] = sync
+    return d
+
+
+def c4fm_iq(
+    n: int,
+    fs: float,
+    seed: int,
+    snr_db: float = 20.0,
+    freq_offset_hz: float = 0.0,
+    symbol_rate: float = 4800.0,
+    frame_len: int = 360,
+    amp: float = 0.5,
+    silence: tuple[int, int] | None = None,
+) -> tuple[np.ndarray, np.ndarray]:
+    """RRC-shaped C4FM at complex baseband (deviation: symbol 3 -> 1800 Hz).
+
+    Returns (iq complex64[n], transmitted dibits).  ``silence=(a, b)`` replaces
+    samples a..b by noise only (exercises fine-sync loss).
+    """
+    sps = fs / symbol_rate
+    n_sym = int(np.ceil(n / sps)) + 24
+    dib = c4fm_frames_dibits(n_sym, seed, frame_len)
+    sym = _DIBIT_TO_SYMBOL[dib]
+    # frequency waveform f(t) = 600 Hz * sum_k a_k p(t/T - k), RRC pulse alpha 0.2, +-8 symbols
+    tn = np.arange(n, dtype=np.float64) / sps
+    freq = np.zeros(n, dtype=np.float64)
+    k0 = np.floor(tn).astype(np.int64)
+    for dk in range(-8, 9):
+        k = k0 + dk
+        ok = (k >= 0) & (k < n_sym)
+        a = np.where(ok, sym[np.clip(k, 0, n_sym - 1)], 0.0)
+        freq += a * _rrc_pulse(tn - k, 0.2)
+    # normalise pulse so that the matched RRC pair gives unit symbol amplitude
+    freq *= 600.0
+    phase = 2 * np.pi * np.cumsum(freq + freq_offset_hz) / fs
+    iq = amp * np.exp(1j * phase)
+    rng = np.random.default_rng(seed + 7919)
+    sigma = amp * 10 ** (-snr_db / 20.0) / np.sqrt(2.0)
+    noise = sigma * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    if silence is not None:
+        a, b = silence
+        iq[a:b] = 0.0
+    return (iq + noise).astype(np.complex64), dib
