@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X demod hot path.
+
+Workload (BASELINE.json configs[2], the config the metric's roofline is quoted on; configs[4]
+when --gpus N > 1): 1024-channel 2x-oversampled polyphase filterbank, fs = 10 MS/s,
+channel_bandwidth = 9765 Hz (M = 1024, 9 taps/arm), complex64 input resident in HBM.
+One step = one pass of the filterbank over one 2^28-sample buffer of synthetic IQ (seeded
+on-device normal noise), followed by the scanner/activity statistics of the last scan window
+(1024 hops) and, for N > 1, their RCCL all-reduce.  One independent device stream per GPU
+(weak scaling, no data-path collective).
+
+metric value = input MS/s x channels demodulated, whole job.
+roofline     = fused pfb1024 kernel: 24 algorithmic bytes per input sample (8 B read + 2 x 8 B
+               written) / HIP-event duration of that kernel, vs 8 TB/s HBM peak.
+cpu_baseline = the numpy oracle's PolyphaseChannelizer.process on a bounded sample, 1 thread.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "wavecap-sdr_amd"), os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+FS = 10_000_000
+BW = 9765
+M = 1024
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+BYTES_PER_SAMPLE = 24.0
+
+
+def cpu_baseline(seconds_budget: float = 12.0):
+    """Oracle (numpy port) timed on the host: PolyphaseChannelizer(10e6, 9765).process."""
+    import numpy as np
+    import signals as S
+    from oracle import ref_np as O
+
+    n = 1 << 21
+    x = S.noise_c64(n, 3)
+    ch = O.PolyphaseChannelizer(FS, BW)
+    ch.process(x[: 1 << 16])
+    ch.reset()
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        ch.process(x)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > seconds_budget or reps >= 8:
+            break
+    msps = reps * n / el / 1e6
+    return {"value": round(msps * M, 1), "unit": "MS/s x channels", "cores": 1, "kind": "port",
+            "sample": f"{reps} x 2^21 complex64 samples through oracle/ref_np.PolyphaseChannelizer "
+                      f"(M=1024, numpy {np.__version__}), {el:.1f} s", "input_msps": round(msps, 2)}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log2n", type=int, default=28, help="samples per step = 2^log2n")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    assert torch.cuda.is_available(), "bench.py needs a ROCm GPU"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import wavehip
+    from wavehip.scanner_reduce import reduce_channel_stats
+
+    n = 1 << args.log2n
+    ch = wavehip.PolyphaseChannelizer(FS, BW)
+    assert ch.channel_count == M
+    gen = torch.Generator(device="cuda").manual_seed(3000 + rank)
+    x = torch.view_as_complex(torch.randn(n, 2, device="cuda", generator=gen).mul_(0.5))
+    hops = ch.hops(n)
+    out = torch.empty((hops, M), dtype=torch.complex64, device="cuda")
+    stats = torch.zeros((M, 5), dtype=torch.float64, device="cuda")
+    scan = min(1024, hops)
+    ch.profile(True)
+
+    def step():
+        ch.process_device(x, out)
+        ch.channel_stats_device(out[hops - scan:], stats)
+        return reduce_channel_stats(stats) if world > 1 else stats
+
+    for _ in range(args.warmup):
+        step()
+    kernel_ms = []
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        kernel_ms.append(ch.last_kernel_ms())      # waits for that step's fused kernel only
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * n * args.steps / elapsed / 1e6 * M
+        k_ms = sum(kernel_ms) / len(kernel_ms)
+        fused_samples = ((hops - 8) // 4) * 4 * 512           # samples consumed by the fused kernel's hops
+        achieved = BYTES_PER_SAMPLE * fused_samples / (k_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "input IQ MS/s x channels demodulated (1024-channel polyphase filterbank)",
+            "value": round(value, 1), "unit": "MS/s x channels", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "1024-channel polyphase filterbank, 10 MS/s cf32, channel_bandwidth 9765, "
+                                   f"2^{args.log2n} samples per step per GPU, one stream per GPU "
+                                   "(BASELINE.json configs[2] / configs[4])",
+                       "samples_per_step_per_gpu": n, "hops_per_step": hops, "channels": M,
+                       "scan_window_hops": scan, "collective": "rccl all_reduce(stats)" if world > 1 else "none"},
+            "input_msps": round(world * n * args.steps / elapsed / 1e6, 1),
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "kernel": "pfb1024_kernel", "kernel_ms": round(k_ms, 4),
+                         "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * fused_samples},
+        }
+        if world == 1 and not args.no_cpu:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

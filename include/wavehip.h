@@ -1,0 +1,156 @@
+/*
+ * wavehip.h -- C ABI of libwavehip.so, the MI355X (gfx950) implementation of
+ * WaveCap-SDR's per-channel DSP hot path.
+ *
+ * Conventions
+ *   - every pointer named d_* is a DEVICE pointer (HBM) owned by the caller; every
+ *     pointer named h_* is a host pointer read during the call only;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only
+ *     enqueue work, they never synchronise the device;
+ *   - return value: 0 = ok, <0 = WH_E_* ; wh_last_error() gives a thread-local text;
+ *   - no global mutable state: handles may be used from different host threads as
+ *     long as one handle is used by one thread at a time (the reference calls the
+ *     channel operator from a 3-thread pool, capture.py:1906-1925);
+ *   - complex samples are interleaved float32 (re, im) == numpy complex64.
+ *
+ * Every entry point cites the reference interface it replaces (paths relative to
+ * the reference checkout, backend/wavecapsdr/...).
+ */
+#ifndef WAVEHIP_H
+#define WAVEHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WH_OK 0
+#define WH_E_ARG (-1)      /* bad argument / unsupported size */
+#define WH_E_HIP (-2)      /* HIP runtime error (text in wh_last_error) */
+#define WH_E_NOMEM (-3)
+
+int wh_abi_version(void);            /* bumps when a signature changes */
+const char *wh_last_error(void);     /* thread-local, never NULL */
+int wh_device_info(int *cu_count, int *lds_bytes, char *name, size_t name_len);
+
+/* ---- A1: int16 IQ wire conventions ------------------------------------------------
+ * unpack: cli.py:447-452, harness.py:274   (int16 -> f32 / 32768.0, I,Q interleaved)
+ * pack  : capture.py:102-116 pack_iq16     (clip(-1,1) * 32767.0 -> int16, truncation)
+ * pcm16 : capture.py:119-131 pack_pcm16                                              */
+int wh_unpack_i16_cf32(const int16_t *d_in, float *d_out, size_t n_complex, void *stream);
+int wh_pack_cf32_i16(const float *d_in, int16_t *d_out, size_t n_complex, void *stream);
+int wh_pack_f32_pcm16(const float *d_in, int16_t *d_out, size_t n, void *stream);
+
+/* ---- A2: stateless NCO mix, capture.py:166-193 freq_shift -------------------------
+ * phase[n] = f32(-2 pi off/fs) * f32(n) (float32 product), restarted every call.     */
+int wh_nco_mix(const float *d_iq, float *d_out, size_t n, int offset_hz, int sample_rate,
+               void *stream);
+
+/* ---- A3: FM discriminator, dsp/fm.py:65-97 quadrature_demod ----------------------- */
+int wh_fm_discriminate(const float *d_iq, float *d_out, size_t n, int sample_rate, void *stream);
+
+/* ---- A6: rational resampler, dsp/fm.py:184-221 resample_poly ----------------------
+ * h_taps: float64[ntaps] = firwin(...)*up exactly as scipy.signal.resample_poly builds
+ * them; d0: alignment so that y[m] = sum_j h[j]*xup[m*down + d0 - j].
+ * d_x: float32[batch][n_in]  ->  d_y: float32[batch][n_out].                         */
+typedef struct wh_resampler wh_resampler;
+int wh_resampler_create(wh_resampler **out, const double *h_taps, int ntaps, int up, int down, int d0);
+int wh_resampler_run(wh_resampler *r, const float *d_x, size_t n_in, size_t batch, float *d_y,
+                     size_t n_out, void *stream);
+void wh_resampler_destroy(wh_resampler *r);
+
+/* ---- Channel operator, batched: capture.py:298-439 _process_channel_dsp_stateless
+ * for modes "nbfm"/"wbfm" over K channels of one capture (replaces the per-channel
+ * ThreadPoolExecutor fan-out of capture.py:2489-2597).
+ *   input : one chunk-major IQ buffer shared by all channels, int16 interleaved
+ *           (format 1, A1 unpack rule fused) or complex64 (format 0);
+ *   output: d_audio float32[n_chunks][K][n_out], d_metrics float32[n_chunks][K][4] =
+ *           {rssi_db, signal_power_db, max_abs_audio, finite_flag} (capture.py:331-334,
+ *           432-437; validation.py:41-52 is applied by the host shim from the last two).
+ * mode: 0 = nbfm (all optional filters off = NBFM mode default, capture.py:3444-3452)
+ *       1 = wbfm (de-emphasis + MPX low-pass, WBFM mode default); IIR coefficients
+ *           are given by the host: deemph_b0/a1 (float32 one-pole, dsp/fm.py:101-108),
+ *           mpx_b/mpx_a float64[6] (butter(5), dsp/fm.py:129-144), NULL = stage off.   */
+typedef struct wh_fmbank wh_fmbank;
+typedef struct wh_fmbank_cfg {
+    int sample_rate;
+    int chunk_len;          /* N samples per chunk (capture.py:3035) */
+    int n_channels;
+    const int *h_offsets_hz;/* round(offset_hz) per channel; 0 = no mix (capture.py:328) */
+    int input_format;       /* 0 = complex64, 1 = int16 IQ */
+    int mode;               /* 0 nbfm, 1 wbfm */
+    const double *h_taps;   /* resample_poly taps (see wh_resampler_create) */
+    int ntaps, up, down, d0;
+    int n_out;              /* ceil(N*up/down) */
+    float deemph_b0;        /* wbfm only: float32 b[0] of dsp/fm.py:106; <=0 disables */
+    float deemph_a1;        /* wbfm only: float32 a[1] = -(1-alpha) of dsp/fm.py:107 */
+    const double *h_mpx_b;  /* wbfm only; NULL disables */
+    const double *h_mpx_a;
+} wh_fmbank_cfg;
+int wh_fmbank_create(wh_fmbank **out, const wh_fmbank_cfg *cfg);
+int wh_fmbank_run(wh_fmbank *b, const void *d_in, size_t n_chunks, float *d_audio, float *d_metrics,
+                  void *stream);
+size_t wh_fmbank_workspace_bytes(const wh_fmbank *b, size_t n_chunks);
+void wh_fmbank_destroy(wh_fmbank *b);
+
+/* ---- A7: polyphase channelizer, dsp/channelizer.py:28-158 PolyphaseChannelizer ----
+ * h_arms: float64[M][T] exactly as _design_filter builds them (channelizer.py:69-89).
+ * run(): processes (n-M)/(M/2)+1 hops, writes complex64 d_out[hops][M] (row h == the
+ * reference's results[h]), updates the carried arm history (9 columns, col j = block
+ * h-1-j) and optionally accumulates per-channel activity statistics.                 */
+typedef struct wh_pfb wh_pfb;
+int wh_pfb_create(wh_pfb **out, int channel_count, int taps_per_channel, const double *h_arms);
+size_t wh_pfb_hops(const wh_pfb *p, size_t n_samples);
+int wh_pfb_run(wh_pfb *p, const float *d_iq, size_t n_samples, float *d_out, void *stream);
+int wh_pfb_reset(wh_pfb *p, void *stream);                       /* channelizer.py:139-142 */
+int wh_pfb_get_history(wh_pfb *p, float *h_hist /* c64[M][T] */, void *stream);
+int wh_pfb_set_history(wh_pfb *p, const float *h_hist, void *stream);
+/* measurement aid (bench.py roofline): when enabled, run() brackets the fused M=1024 kernel
+ * with HIP events on the caller's stream; kernel_ms() waits for and returns the duration of
+ * the most recent one. */
+int wh_pfb_profile(wh_pfb *p, int enable);
+int wh_pfb_kernel_ms(wh_pfb *p, float *ms);
+/* extract_channel, channelizer.py:144-158: d_col[h] = d_out[h][idx] */
+int wh_pfb_extract_channel(const float *d_out, size_t hops, int channel_count, int idx, float *d_col,
+                           void *stream);
+/* A13 activity statistics over a filterbank output block (BinStats fields of
+ * channel_classifier.py:17-48 per channel): d_stats float64[M][5] =
+ * {sum p, sum p^2, count, min p, max p}, p = |y|^2; accumulate != 0 merges into d_stats. */
+int wh_pfb_channel_stats(const float *d_out, size_t hops, int channel_count, double *d_stats,
+                         int accumulate, void *stream);
+
+/* ---- A8: spectrum, dsp/fft/scipy_backend.py:38-79 ScipyFFTBackend.execute ---------
+ * d_iq: complex64, frame f starts at d_iq + f*frame_stride (complex units); uses the
+ * first fft_size samples; d_power_db float32[n_frames][fft_size], fft-shifted,
+ * 20*log10(|X| + 1e-10) with a symmetric Hann window (dsp/fft/base.py:54-59).        */
+typedef struct wh_spectrum wh_spectrum;
+int wh_spectrum_create(wh_spectrum **out, int fft_size);
+int wh_spectrum_run(wh_spectrum *s, const float *d_iq, size_t n_frames, size_t frame_stride,
+                    float *d_power_db, void *stream);
+void wh_spectrum_destroy(wh_spectrum *s);
+
+void wh_pfb_destroy(wh_pfb *p);
+
+/* ---- A9-A11: P25 C4FM demodulator bank, dsp/p25/c4fm.py:2379-2807 ------------------
+ * One independent C4FMDemodulator per channel (ctor c4fm.py:2412-2503).  Filters are
+ * designed by the host exactly as the reference does (remez / RRC) and passed in.
+ * run(): every channel consumes n samples (complex64, d_iq[ch][n], row stride
+ * `iq_stride` complex) and appends its dibits / soft symbols to d_dibits[ch][cap] /
+ * d_soft[ch][cap]; d_counts[ch] = symbols produced by this call.  State (filter zi,
+ * 65536-sample phase buffer, sample_point, equaliser, sync rings) is carried on the
+ * device between calls; reset() == C4FMDemodulator.reset() (c4fm.py:2505-2521).      */
+typedef struct wh_c4fm_bank wh_c4fm_bank;
+int wh_c4fm_bank_create(wh_c4fm_bank **out, int n_channels, double samples_per_symbol,
+                        const float *h_lpf, int n_lpf, const float *h_rrc, int n_rrc,
+                        const float *h_interp_taps /* float32[129][8] */, int max_samples_per_call);
+int wh_c4fm_bank_run(wh_c4fm_bank *b, const float *d_iq, size_t n, size_t iq_stride,
+                     uint8_t *d_dibits, float *d_soft, size_t out_cap, int32_t *d_counts, void *stream);
+int wh_c4fm_bank_reset(wh_c4fm_bank *b, void *stream);
+void wh_c4fm_bank_destroy(wh_c4fm_bank *b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WAVEHIP_H */

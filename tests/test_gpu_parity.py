@@ -1,0 +1,281 @@
+"""GPU parity tests: the HIP path (through the C ABI / host shims) against the golden
+vectors captured from the reference and against the CPU oracle on seeded inputs.
+
+Tolerances: bit-exact for int16 pack/unpack; TOL = 1e-5 peak-relative for float outputs
+(north_star)."""
+
+import numpy as np
+import pytest
+
+import signals as S
+from conftest import peak_rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def wh():
+    import torch
+
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    import wavehip
+
+    return wavehip
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import ref_np
+
+    return ref_np
+
+
+def test_a1_int16_bit_exact(wh, golden, O):
+    g = golden("a1_int16")
+    i16 = g["i16"]
+    inter = np.stack([i16, i16[::-1]], axis=1).reshape(-1)
+    z = wh.unpack_iq16(inter)
+    assert np.array_equal(z.real, g["unpack_f32"]) and np.array_equal(z.imag, g["unpack_f32"][::-1])
+    assert np.array_equal(np.frombuffer(wh.pack_iq16(g["pack_in"]), dtype=np.int16), g["pack_out"])
+    assert np.array_equal(np.frombuffer(wh.pack_pcm16(g["pcm_in"]), dtype=np.int16), g["pcm_out"])
+    # round trip on a large random buffer against the oracle
+    x = S.noise_c64(1 << 20, 5, amp=0.4)
+    p = np.frombuffer(wh.pack_iq16(x), dtype=np.int16)
+    assert np.array_equal(p, O.pack_iq16(x))
+    assert np.array_equal(wh.unpack_iq16(p), O.unpack_iq16(p))
+    assert wh.pack_iq16(np.empty(0, np.complex64)) == b""
+
+
+def _nco(wh, iq, off, fs):
+    import torch
+    from wavehip import _lib
+
+    d = torch.from_numpy(iq).cuda()
+    o = torch.empty_like(d)
+    _lib.check(_lib.lib.wh_nco_mix(d.data_ptr(), o.data_ptr(), d.numel(), int(off), int(fs), _lib.stream_ptr(torch)))
+    return o.cpu().numpy()
+
+
+def test_a2_nco(wh, golden, O):
+    g = golden("a2_nco")
+    for ci in range(int(g["n_cases"])):
+        n, off, fs, seed = (int(v) for v in g[f"c{ci}_args"])
+        iq = S.noise_c64(n, seed)
+        idx = g[f"c{ci}_idx"]
+        y = _nco(wh, iq, off, fs)
+        assert peak_rel_err(y[idx], g[f"c{ci}_y"]) <= TOL
+        assert peak_rel_err(y, O.freq_shift(iq, float(off), fs)) <= TOL
+    # the phasor itself (unit input) against the reference table: catches a float64-phase NCO
+    n, off, fs, _ = (int(v) for v in g["c0_args"])
+    tab = _nco(wh, np.ones(n, np.complex64), off, fs)
+    assert np.max(np.abs(tab[g["c0_idx"]] - g["c0_tab"])) <= 1e-6
+
+
+def test_a3_discriminator(wh, golden, O):
+    import torch
+    from wavehip import _lib
+
+    g = golden("a3_quad")
+    for iq, fs, y in ((g["iq"], int(g["fs"]), g["y"]), (g["iq2"], int(g["fs2"]), g["y2"])):
+        d = torch.from_numpy(iq).cuda()
+        o = torch.empty(d.numel(), dtype=torch.float32, device="cuda")
+        _lib.check(_lib.lib.wh_fm_discriminate(d.data_ptr(), o.data_ptr(), d.numel(), fs, _lib.stream_ptr(torch)))
+        assert peak_rel_err(o.cpu().numpy(), y) <= TOL
+
+
+def test_a6_resample(wh, golden, O):
+    import ctypes as C
+
+    import torch
+    from wavehip import _lib
+    from wavehip.channel_ops import resample_design
+
+    g = golden("a6_resample")
+    for ci in range(int(g["n_cases"])):
+        fi, fo, n, seed = (int(v) for v in g[f"c{ci}_args"])
+        x = (np.random.default_rng(seed).standard_normal(n) * 0.3).astype(np.float32)
+        h, up, down, d0 = resample_design(fi, fo)
+        n_out = len(g[f"c{ci}_y"])
+        r = C.c_void_p()
+        _lib.check(_lib.lib.wh_resampler_create(C.byref(r), _lib.dptr(h, "f64"), len(h), up, down, d0))
+        xb = np.stack([x, -0.5 * x])                       # batch of 2 rows
+        d = torch.from_numpy(xb).cuda()
+        o = torch.empty((2, n_out), dtype=torch.float32, device="cuda")
+        _lib.check(_lib.lib.wh_resampler_run(r, d.data_ptr(), n, 2, o.data_ptr(), n_out, _lib.stream_ptr(torch)))
+        y = o.cpu().numpy()
+        _lib.lib.wh_resampler_destroy(r)
+        assert peak_rel_err(y[0], g[f"c{ci}_y"]) <= TOL
+        assert peak_rel_err(y[1], -0.5 * g[f"c{ci}_y"]) <= TOL
+
+
+def _nbfm_cfg(wh, off):
+    return wh.ChannelConfig(id="g", mode="nbfm", offset_hz=float(off), enable_deemphasis=False,
+                            enable_mpx_filter=False)
+
+
+def test_chain_nbfm_golden_int16_bank(wh, golden, O):
+    """Config 2 shape: one int16 stream, 32 NBFM channels, against reference goldens (3 channels)
+    and the oracle (all 32)."""
+    g = golden("chain_analog")
+    fs, n, seed0 = (int(v) for v in g["nbfm_args"])
+    offs = S.nbfm_bank_offsets()
+    bank = wh.ChannelBank(fs, n, [_nbfm_cfg(wh, o) for o in offs], input_format="int16")
+    for chunk in range(2):
+        i16 = S.pack_iq16_np(S.nbfm_bank_c64(n, fs, seed=seed0 + chunk, start=chunk * n))
+        res = bank.process(i16)
+        for k in g["nbfm_k"]:
+            audio, met = res[int(k)]
+            assert peak_rel_err(audio, g[f"nbfm{chunk}_k{k}_audio"]) <= TOL
+            assert np.allclose([met["rssi_db"], met["signal_power_db"]], g[f"nbfm{chunk}_k{k}_met"], atol=2e-4)
+        if chunk == 0:
+            z = O.unpack_iq16(i16)
+            for k in range(32):
+                a_ref, m_ref = O.process_channel_nbfm(z, fs, offs[k])
+                assert peak_rel_err(res[k][0], a_ref) <= TOL, k
+                assert abs(res[k][1]["rssi_db"] - m_ref["rssi_db"]) <= 2e-4
+
+
+def test_chain_nbfm_single_channel_dropin(wh, golden):
+    g = golden("chain_analog")
+    fs, n, seed0 = (int(v) for v in g["nbfm_args"])
+    offs = S.nbfm_bank_offsets()
+    i16 = S.pack_iq16_np(S.nbfm_bank_c64(n, fs, seed=seed0, start=0))
+    z = wh.unpack_iq16(i16)
+    audio, met = wh.process_channel_dsp_stateless(z, fs, _nbfm_cfg(wh, offs[13]))
+    assert audio.dtype == np.float32 and audio.shape == (2400,)
+    assert peak_rel_err(audio, g["nbfm0_k13_audio"]) <= TOL
+    # error conventions (capture.py:321-325)
+    assert wh.process_channel_dsp_stateless(np.empty(0, np.complex64), fs, _nbfm_cfg(wh, 0)) == (None, {})
+    bad = z.copy()
+    bad[100] = np.nan
+    assert wh.process_channel_dsp_stateless(bad, fs, _nbfm_cfg(wh, offs[13])) == (None, {})
+    with pytest.raises(NotImplementedError):
+        wh.process_channel_dsp_stateless(z, fs, wh.ChannelConfig(mode="sam"))
+
+
+def test_chain_nbfm_multichunk_matches_single(wh):
+    """n_chunks in one launch == chunk-by-chunk (stateless per chunk, capture.py:298)."""
+    import torch
+
+    fs, n = 2400000, 120000
+    offs = S.nbfm_bank_offsets(8)
+    bank = wh.ChannelBank(fs, n, [_nbfm_cfg(wh, o) for o in offs], input_format="int16")
+    i16 = np.concatenate([S.pack_iq16_np(S.nbfm_bank_c64(n, fs, seed=40 + c, n_ch=8, start=c * n)) for c in range(3)])
+    a3, m3 = bank.process_device(torch.from_numpy(i16).cuda(), 3)
+    a3 = a3.cpu().numpy()
+    for c in range(3):
+        a1, _ = bank.process_device(torch.from_numpy(i16[2 * n * c: 2 * n * (c + 1)].copy()).cuda(), 1)
+        assert np.array_equal(a1.cpu().numpy()[0], a3[c])
+
+
+def test_chain_wbfm(wh, golden):
+    g = golden("chain_analog")
+    for ci in range(2):
+        fs, n, seed, off = (int(v) for v in g[f"wbfm{ci}_args"])
+        iq = S.fm_tone_c64(n, fs, seed=seed, carrier_hz=float(off))
+        cfg = wh.ChannelConfig(id="w", mode="wbfm", offset_hz=float(off))
+        audio, met = wh.process_channel_dsp_stateless(iq, fs, cfg)
+        assert peak_rel_err(audio, g[f"wbfm{ci}_audio"]) <= TOL
+        assert np.allclose([met["rssi_db"], met["signal_power_db"]], g[f"wbfm{ci}_met"], atol=2e-4)
+
+
+def test_a7_pfb_golden(wh, golden):
+    g = golden("a7_pfb")
+    for ci in range(int(g["n_cases"])):
+        fs, bw, M, seed, n1, n2 = (int(v) for v in g[f"c{ci}_args"])
+        x = S.noise_c64(n1 + n2, seed)
+        ch = wh.PolyphaseChannelizer(fs, bw)
+        assert ch.channel_count == M and S.sha256(ch.arms) == str(g[f"c{ci}_arms_sha"])
+        r1 = ch.process(x[:n1])
+        r2 = ch.process(x[n1:])
+        assert r1.shape == g[f"c{ci}_r1"].shape and r2.shape == g[f"c{ci}_r2"].shape
+        assert peak_rel_err(r1, g[f"c{ci}_r1"]) <= TOL
+        assert peak_rel_err(r2, g[f"c{ci}_r2"]) <= TOL
+        assert np.array_equal(ch.arm_history, g[f"c{ci}_hist"])
+        assert peak_rel_err(ch.extract_channel(r1, 5), g[f"c{ci}_ex5"]) <= TOL
+        assert len(list(r1)) == r1.shape[0] and r1[0].shape == (M,)      # list-like view
+        ch.reset()
+        assert not ch.arm_history.any()
+    ch = wh.PolyphaseChannelizer(1_000_000, 25000)
+    assert len(ch.process(S.noise_c64(39, 1))) == 0
+
+
+@pytest.mark.parametrize("n", [1024 * 9 + 512 * 3, 1024 * 300 + 77, 512 * 4099 + 1024])
+def test_a7_pfb_fast_path_vs_oracle(wh, O, n):
+    """M=1024 sizes that exercise the fused kernel (hops >= 8), its ragged tail and the
+    carried history across two calls."""
+    x = S.noise_c64(n + 5000, 77)
+    ch = wh.PolyphaseChannelizer(10_000_000, 9765)
+    ref = O.PolyphaseChannelizer(10_000_000, 9765)
+    for part in (x[:n], x[n:]):
+        a, b = ch.process(part), ref.process(part)
+        assert a.shape == b.shape
+        assert peak_rel_err(a, b) <= TOL
+    assert np.array_equal(ch.arm_history, ref.arm_history)
+
+
+def test_a7_pfb_properties_large(wh):
+    """Size-independent properties at a size the oracle would not finish quickly:
+    linearity and the response to a single complex tone (energy lands in one channel)."""
+    import torch
+
+    n = 1 << 24
+    ch = wh.PolyphaseChannelizer(10_000_000, 9765)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    a = torch.randn(n, 2, device="cuda", generator=g).mul_(0.5)
+    b = torch.randn(n, 2, device="cuda", generator=g).mul_(0.5)
+    xa, xb = torch.view_as_complex(a), torch.view_as_complex(b)
+    ya = ch.process_device(xa).clone(); ch.reset()
+    yb = ch.process_device(xb).clone(); ch.reset()
+    ys = ch.process_device(xa * 0.5 + xb * 2.0); ch.reset()
+    err = (ys - (ya * 0.5 + yb * 2.0)).abs().max().item() / ys.abs().max().item()
+    assert err <= 1e-5
+    # tone at the centre of channel 37: x[n] = exp(2 pi i 37 n / 1024)
+    k = 37
+    t = torch.arange(n, device="cuda", dtype=torch.float64)
+    ph = 2 * np.pi * ((t * k) % 1024) / 1024
+    tone = torch.complex(torch.cos(ph), torch.sin(ph)).to(torch.complex64)
+    yt = ch.process_device(tone)
+    p = (yt[16:].abs() ** 2).mean(0)
+    assert int(p.argmax()) == k
+    assert p[k].item() > 0.75 * p.sum().item()   # the reference's structure leaks into k+-1 (no per-hop shift)
+
+
+def test_a8_spectrum(wh, golden):
+    g = golden("a8_spectrum")
+    for ci in range(int(g["n_cases"])):
+        N, fs, seed = (int(v) for v in g[f"c{ci}_args"])
+        iq = S.fm_tone_c64(N + 100, fs, seed=seed, deviation=20000.0, carrier_hz=123456.0, noise_amp=0.01)
+        be = wh.HipFFTBackend(N)
+        r = be.execute(iq, fs)
+        assert be.name == "hip" and r.power_db.dtype == np.float32 and r.freqs.dtype == np.float32
+        ref = g[f"c{ci}_power"]
+        lin, lin_ref = 10.0 ** (r.power_db / 20.0), 10.0 ** (ref / 20.0)
+        assert peak_rel_err(lin, lin_ref) <= TOL                     # magnitude, peak-relative
+        strong = ref > ref.max() - 60.0
+        assert np.max(np.abs(r.power_db[strong] - ref[strong])) <= 0.01   # dB on bins within 60 dB
+        assert int(np.argmax(r.power_db)) == int(np.argmax(ref))
+        assert np.array_equal(r.freqs, g[f"c{ci}_freqs"]) and r.bin_hz == float(g[f"c{ci}_bin"])
+    r = wh.HipFFTBackend(1024).execute(S.noise_c64(100, 1), 2400000)     # short input -> zeros
+    assert not r.power_db.any() and not r.freqs.any()
+    # non power of two size goes through the direct DFT
+    be = wh.HipFFTBackend(1000)
+    iq = S.fm_tone_c64(1000, 1_000_000, seed=9, deviation=5000.0, carrier_hz=50_000.0)
+    from oracle import ref_np as O
+    p, f, b = O.spectrum(iq, 1_000_000, 1000)
+    r = be.execute(iq, 1_000_000)
+    assert peak_rel_err(10.0 ** (r.power_db / 20.0), 10.0 ** (p / 20.0)) <= TOL
+
+
+def test_a13_channel_stats(wh, O):
+    import torch
+
+    x = S.noise_c64(1024 * 64, 91)
+    ch = wh.PolyphaseChannelizer(10_000_000, 9765)
+    y = ch.process_device(torch.from_numpy(x).cuda())
+    st = ch.channel_stats_device(y).cpu().numpy()
+    ref = O.pfb_channel_stats(y.cpu().numpy())
+    assert np.allclose(st, ref, rtol=1e-9, atol=0)
+    st2 = ch.channel_stats_device(y, torch.from_numpy(st.copy()).cuda(), accumulate=True).cpu().numpy()
+    assert np.allclose(st2[:, :3], 2 * ref[:, :3], rtol=1e-9) and np.allclose(st2[:, 3:], ref[:, 3:], rtol=1e-12)

@@ -1,0 +1,586 @@
+// Analog per-channel chain for gfx950: int16 unpack/pack (A1), stateless NCO (A2), FM
+// discriminator (A3), rational resampler (A6) and the batched channel operator ("fmbank",
+// reference capture.py:298-439 for modes nbfm / wbfm).
+//
+// fmbank fused kernel (up == 1, nbfm): one workgroup = (chunk, channel, tile of TO outputs).
+//   phase 1  NCO mix + discriminator for the tile's span of input samples, straight from the
+//            shared int16 / complex64 chunk (coalesced), neighbour sample x[n-1] taken from the
+//            previous lane with a wavefront shuffle (each wave advances 63 samples), fm kept in LDS;
+//   phase 2  the decimating FIR (resample_poly taps, float64 accumulation like scipy) computed
+//            only at the kept outputs, from LDS;
+//   the RMS normalisation commutes with the FIR, so its scale (which needs the whole chunk) and
+//   the tanh soft clip are applied by a tiny finalize kernel that also produces the metrics.
+// HBM traffic: the input chunk (4 or 8 B per sample, shared by all channels through L2) and
+// n_out floats per channel -- no intermediate fm array.
+#include "wh_common.h"
+#include "wh_portable_math.h"
+#include <cmath>
+#include <vector>
+
+using namespace wh;
+
+namespace {
+
+__device__ __forceinline__ float2 load_iq(const void *in, int fmt, size_t idx) {
+    if (fmt == 1) {
+        short2 v = reinterpret_cast<const short2 *>(in)[idx];
+        // A1 unpack rule: int16 -> float32 / 32768.0 (exact)
+        return make_float2((float)v.x * (1.0f / 32768.0f), (float)v.y * (1.0f / 32768.0f));
+    }
+    return reinterpret_cast<const float2 *>(in)[idx];
+}
+
+// base[n] = x[n] * exp(i * f32(c) * f32(n))   (capture.py:166-193; c already negative)
+__device__ __forceinline__ float2 mix(float2 x, float c, int n, bool do_mix) {
+    if (!do_mix) return x;
+    float ph = __fmul_rn(c, (float)n);
+    float s, co;
+    whm_sincos_phase(ph, &s, &co);
+    return make_float2(x.x * co - x.y * s, x.x * s + x.y * co);
+}
+
+__global__ void unpack_kernel(const short2 *in, float2 *out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        short2 v = in[i];
+        out[i] = make_float2((float)v.x * (1.0f / 32768.0f), (float)v.y * (1.0f / 32768.0f));
+    }
+}
+
+__device__ __forceinline__ short pack1(float f) {
+    // np.clip(-1, 1) then * 32767.0 then C cast (truncate toward zero); NaN -> clip keeps NaN,
+    // numpy's x86 cast of NaN (cvttss2si -> 0x80000000, low 16 bits) gives 0: mirror it.
+    if (f != f) return (short)0;
+    f = fminf(fmaxf(f, -1.0f), 1.0f);
+    return (short)(int)(__fmul_rn(f, 32767.0f));
+}
+
+__global__ void pack_iq_kernel(const float2 *in, short2 *out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        float2 v = in[i];
+        short2 o;
+        o.x = pack1(v.x);
+        o.y = pack1(v.y);
+        out[i] = o;
+    }
+}
+
+__global__ void pack_pcm_kernel(const float *in, short *out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = pack1(in[i]);
+}
+
+__global__ void nco_kernel(const float2 *in, float2 *out, size_t n, float c) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = mix(in[i], c, (int)i, true);
+}
+
+__global__ void disc_kernel(const float2 *in, float *out, size_t n, float scale) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        float v = 0.f;
+        if (i > 0) {
+            float2 a = in[i], b = in[i - 1];
+            float re = a.x * b.x + a.y * b.y;
+            float im = a.y * b.x - a.x * b.y;
+            v = whm_atan2f(im, re) * scale;
+        }
+        out[i] = v;
+    }
+}
+
+// ---- generic rational resampler: one wave per output ---------------------------------------
+__global__ __launch_bounds__(256) void resample_kernel(const float *x, size_t n_in, float *y, size_t n_out,
+                                                       const double *h, int ntaps, int up, int down, int d0) {
+    const int lane = threadIdx.x & 63;
+    const size_t m = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t b = blockIdx.y;
+    if (m >= n_out) return;
+    const float *xb = x + b * n_in;
+    long long base = (long long)m * down + d0;
+    int j0 = (int)(base % up);
+    long long q0 = (base - j0) / up;
+    int cnt = (ntaps - 1 - j0) / up + 1;  // taps j0 + up*i < ntaps
+    if (j0 > ntaps - 1) cnt = 0;
+    double acc = 0.0;
+    for (int i = lane; i < cnt; i += 64) {
+        long long q = q0 - i;
+        if (q >= 0 && q < (long long)n_in) acc = fma((double)xb[q], h[j0 + up * i], acc);
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) y[b * n_out + m] = (float)acc;
+}
+
+// ---- fmbank ---------------------------------------------------------------------------------
+struct FmArgs {
+    const void *in;     // [n_chunks][N] int16x2 or float2
+    float *audio;       // [n_chunks][K][n_out]   (unscaled FIR output until finalize)
+    double *acc;        // [n_chunks][K][2] = {sum |base|^2, sum fm^2}
+    float *fm_out;      // unfused path: [n_chunks][K][N] discriminator output
+    const float *nco_c; // [K] f32(-2 pi off/fs); 0 => no mix
+    const double *taps; // [ntaps]
+    int fmt, N, K, n_out, ntaps, down, d0, TO;
+    float scale;        // fs / (2 pi 75000)
+};
+
+constexpr int FM_MAX_SPAN = 8192;    // floats of fm kept in LDS (32 KiB -> 4 workgroups per CU)
+constexpr int FM_MAX_TAPS = 2048;    // float64 taps kept in LDS (16 KiB)
+
+__global__ __launch_bounds__(256) void fmbank_fused_kernel(FmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double *taps_s = reinterpret_cast<double *>(smem_raw);
+    float *fm_s = reinterpret_cast<float *>(smem_raw + (size_t)a.ntaps * sizeof(double));
+    __shared__ double red[8];
+
+    const int tile = blockIdx.x, k = blockIdx.y, chunk = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = a.N;
+    const int m0 = tile * a.TO;
+    int mcnt = a.n_out - m0;
+    if (mcnt > a.TO) mcnt = a.TO;
+    const int n_lo = m0 * a.down + a.d0 - (a.ntaps - 1);
+    const int span = a.ntaps + (mcnt - 1) * a.down;
+    const int own_lo = m0 * a.down;
+    int own_hi = (m0 + a.TO) * a.down;  // exclusive
+    if (own_hi > N || m0 + a.TO >= a.n_out) own_hi = N;
+
+    for (int j = tid; j < a.ntaps; j += 256) taps_s[j] = a.taps[j];
+
+    const float c = a.nco_c[k];
+    const bool do_mix = c != 0.0f;
+    const size_t in_base = (size_t)chunk * N;
+    float p_base = 0.f, p_fm = 0.f;
+    // phase 1: each wave covers 63 samples per step; lane 0 only supplies x[n-1]
+    for (int s0 = wave * 63; s0 < span; s0 += 4 * 63) {
+        int i = s0 + lane - 1;          // span index (lane 0 -> previous sample)
+        int n = n_lo + i;               // chunk sample index
+        bool valid = (n >= 0) && (n < N);
+        float2 bse = make_float2(0.f, 0.f);
+        if (valid) bse = mix(load_iq(a.in, a.fmt, in_base + n), c, n, do_mix);
+        float2 prv;
+        prv.x = __shfl_up(bse.x, 1);
+        prv.y = __shfl_up(bse.y, 1);
+        if (lane > 0 && i < span) {
+            float v = 0.f;
+            if (valid && n >= 1) {
+                float re = bse.x * prv.x + bse.y * prv.y;
+                float im = bse.y * prv.x - bse.x * prv.y;
+                v = whm_atan2f(im, re) * a.scale;
+            }
+            fm_s[i] = v;
+            if (valid && n >= own_lo && n < own_hi) {
+                p_base += bse.x * bse.x + bse.y * bse.y;
+                p_fm += v * v;
+            }
+        }
+    }
+    // block-reduce the two power sums (float64) and publish with one atomic pair
+    double db = (double)p_base, df = (double)p_fm;
+    for (int o = 32; o > 0; o >>= 1) {
+        db += __shfl_xor(db, o);
+        df += __shfl_xor(df, o);
+    }
+    if (lane == 0) {
+        red[wave] = db;
+        red[4 + wave] = df;
+    }
+    __syncthreads();  // also makes fm_s / taps_s visible
+    if (tid == 0) {
+        double *acc = a.acc + ((size_t)chunk * a.K + k) * 2;
+        atomicAdd(acc, red[0] + red[1] + red[2] + red[3]);
+        atomicAdd(acc + 1, red[4] + red[5] + red[6] + red[7]);
+    }
+    // phase 2: S = 256/TO lanes share one output; y[m] = sum_j h[j] * fm[(m-m0)*down + ntaps-1-j]
+    const int S = 256 / a.TO;
+    const int o = tid / S, sub = tid - o * S;
+    double accv = 0.0;
+    if (o < mcnt) {
+        const float *f = fm_s + o * a.down + (a.ntaps - 1);
+        for (int j = sub; j < a.ntaps; j += S) accv = fma((double)f[-j], taps_s[j], accv);
+    }
+    for (int w = 1; w < S; w <<= 1) accv += __shfl_xor(accv, w);
+    if (o < mcnt && sub == 0) a.audio[((size_t)chunk * a.K + k) * a.n_out + m0 + o] = (float)accv;
+}
+
+// unfused first stage (wbfm, or up != 1): discriminator to HBM + power sums
+__global__ __launch_bounds__(256) void fmbank_disc_kernel(FmArgs a) {
+    const int k = blockIdx.y, chunk = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = a.N;
+    const float c = a.nco_c[k];
+    const bool do_mix = c != 0.0f;
+    const size_t in_base = (size_t)chunk * N;
+    float *fm = a.fm_out + ((size_t)chunk * a.K + k) * N;
+    __shared__ double red[8];
+    float p_base = 0.f, p_fm = 0.f;
+    const int per_block = 4 * 63 * 16;
+    const int b_lo = blockIdx.x * per_block;
+    int b_hi = b_lo + per_block;
+    if (b_hi > N) b_hi = N;
+    for (int s0 = b_lo + wave * 63; s0 < b_hi; s0 += 4 * 63) {
+        int n = s0 + lane - 1;
+        bool valid = (n >= 0) && (n < N);
+        float2 bse = make_float2(0.f, 0.f);
+        if (valid) bse = mix(load_iq(a.in, a.fmt, in_base + n), c, n, do_mix);
+        float2 prv;
+        prv.x = __shfl_up(bse.x, 1);
+        prv.y = __shfl_up(bse.y, 1);
+        if (lane > 0 && valid && n < b_hi) {
+            float v = 0.f;
+            if (n >= 1) {
+                float re = bse.x * prv.x + bse.y * prv.y;
+                float im = bse.y * prv.x - bse.x * prv.y;
+                v = whm_atan2f(im, re) * a.scale;
+            }
+            fm[n] = v;
+            p_base += bse.x * bse.x + bse.y * bse.y;
+            p_fm += v * v;
+        }
+    }
+    double db = (double)p_base, df = (double)p_fm;
+    for (int o = 32; o > 0; o >>= 1) {
+        db += __shfl_xor(db, o);
+        df += __shfl_xor(df, o);
+    }
+    if (lane == 0) {
+        red[wave] = db;
+        red[4 + wave] = df;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double *acc = a.acc + ((size_t)chunk * a.K + k) * 2;
+        atomicAdd(acc, red[0] + red[1] + red[2] + red[3]);
+        atomicAdd(acc + 1, red[4] + red[5] + red[6] + red[7]);
+    }
+}
+
+// wbfm IIR stages on one (chunk, channel) row, zero initial state (dsp/fm.py:111-181):
+// de-emphasis one-pole in float32 (lfilter DF2T on float32 data), then butter(5) in float64,
+// output rounded to float32 after each stage like the reference's .astype(np.float32).
+// One lane per row; rows are independent (stateless per chunk).  Also re-accumulates sum fm^2.
+__global__ void wbfm_iir_kernel(float *fm, double *acc, int rows, int N, float alpha, float neg_a1,
+                                const double *ba /* b[6], a[6] or null */, int use_mpx) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    float *f = fm + (size_t)r * N;
+    float z1 = 0.f;
+    double b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0;
+    if (use_mpx) {
+        b0 = ba[0]; b1 = ba[1]; b2 = ba[2]; b3 = ba[3]; b4 = ba[4]; b5 = ba[5];
+        a1 = ba[7]; a2 = ba[8]; a3 = ba[9]; a4 = ba[10]; a5 = ba[11];
+    }
+    double z[5] = {0, 0, 0, 0, 0};
+    double ss = 0.0;
+    for (int n = 0; n < N; ++n) {
+        float x = f[n];
+        if (alpha > 0.f) {
+            // DF2T with b = [b0], a = [1, a1]:  y = b0*x + z ; z = -a1*y
+            float y = __fadd_rn(__fmul_rn(alpha, x), z1);
+            z1 = __fmul_rn(neg_a1, y);
+            x = y;
+        }
+        if (use_mpx) {
+            double xd = (double)x;
+            double y = __dadd_rn(__dmul_rn(b0, xd), z[0]);
+            z[0] = __dsub_rn(__dadd_rn(__dmul_rn(b1, xd), z[1]), __dmul_rn(a1, y));
+            z[1] = __dsub_rn(__dadd_rn(__dmul_rn(b2, xd), z[2]), __dmul_rn(a2, y));
+            z[2] = __dsub_rn(__dadd_rn(__dmul_rn(b3, xd), z[3]), __dmul_rn(a3, y));
+            z[3] = __dsub_rn(__dadd_rn(__dmul_rn(b4, xd), z[4]), __dmul_rn(a4, y));
+            z[4] = __dsub_rn(__dmul_rn(b5, xd), __dmul_rn(a5, y));
+            x = (float)y;
+        }
+        f[n] = x;
+        ss += (double)x * (double)x;
+    }
+    acc[(size_t)r * 2 + 1] = ss;
+}
+
+// finalize: scale by 0.18/rms (dsp/fm.py:42-62), soft clip (fm.py:26-39), metrics
+__global__ __launch_bounds__(256) void fmbank_finalize_kernel(float *audio, const double *acc, float *metrics,
+                                                              int N, int n_out) {
+    const size_t row = blockIdx.x;
+    float *au = audio + row * n_out;
+    const double *ac = acc + row * 2;
+    const float mean_fm = (float)(ac[1] / (double)N);
+    const float rms = sqrtf(mean_fm);
+    float s = 1.0f;
+    if ((double)rms > 1e-4) s = (float)(0.18 / (double)rms);
+    const float NORM = (float)(1.0 / 0.90514825364486640);  // 1/tanh(1.5)
+    float p = 0.f, mx = 0.f;
+    int bad = 0;
+    for (int i = threadIdx.x; i < n_out; i += 256) {
+        float v = au[i] * s;
+        v = tanhf(v * 1.5f) * NORM * 0.95f;
+        au[i] = v;
+        p += v * v;
+        mx = fmaxf(mx, fabsf(v));
+        if (!(fabsf(v) <= 3.0e38f)) bad = 1;
+    }
+    __shared__ float rp[4], rm[4];
+    __shared__ int rb[4];
+    for (int o = 32; o > 0; o >>= 1) {
+        p += __shfl_xor(p, o);
+        mx = fmaxf(mx, __shfl_xor(mx, o));
+        bad |= __shfl_xor(bad, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        rp[threadIdx.x >> 6] = p;
+        rm[threadIdx.x >> 6] = mx;
+        rb[threadIdx.x >> 6] = bad;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        p = rp[0] + rp[1] + rp[2] + rp[3];
+        mx = fmaxf(fmaxf(rm[0], rm[1]), fmaxf(rm[2], rm[3]));
+        bad = rb[0] | rb[1] | rb[2] | rb[3];
+        float *m = metrics + row * 4;
+        m[0] = (float)(10.0 * log10(ac[0] / (double)N + 1e-10));
+        m[1] = (float)(10.0 * log10((double)(p / (float)n_out) + 1e-10));
+        m[2] = mx;
+        m[3] = bad ? 0.f : 1.f;
+    }
+}
+
+inline unsigned grid_for(size_t n) {
+    size_t g = (n + 255) / 256;
+    return (unsigned)(g > 4096 ? 4096 : (g ? g : 1));
+}
+
+}  // namespace
+
+extern "C" int wh_unpack_i16_cf32(const int16_t *d_in, float *d_out, size_t n, void *stream) {
+    if (n == 0) return WH_OK;
+    if (!d_in || !d_out) return set_err(WH_E_ARG, "wh_unpack_i16_cf32: null buffer");
+    hipLaunchKernelGGL(unpack_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const short2 *>(d_in), reinterpret_cast<float2 *>(d_out), n);
+    WH_LAUNCH_CHECK();
+    return WH_OK;
+}
+
+extern "C" int wh_pack_cf32_i16(const float *d_in, int16_t *d_out, size_t n, void *stream) {
+    if (n == 0) return WH_OK;
+    if (!d_in || !d_out) return set_err(WH_E_ARG, "wh_pack_cf32_i16: null buffer");
+    hipLaunchKernelGGL(pack_iq_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float2 *>(d_in), reinterpret_cast<short2 *>(d_out), n);
+    WH_LAUNCH_CHECK();
+    return WH_OK;
+}
+
+extern "C" int wh_pack_f32_pcm16(const float *d_in, int16_t *d_out, size_t n, void *stream) {
+    if (n == 0) return WH_OK;
+    if (!d_in || !d_out) return set_err(WH_E_ARG, "wh_pack_f32_pcm16: null buffer");
+    hipLaunchKernelGGL(pack_pcm_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), d_in,
+                       reinterpret_cast<short *>(d_out), n);
+    WH_LAUNCH_CHECK();
+    return WH_OK;
+}
+
+static float nco_const(int offset_hz, int sample_rate) {
+    // f32(-2 pi (off/fs)) : the Python complex scalar is weak -> cast to complex64 (capture.py:173-176)
+    return (float)(-2.0 * M_PI * ((double)offset_hz / (double)sample_rate));
+}
+
+extern "C" int wh_nco_mix(const float *d_iq, float *d_out, size_t n, int offset_hz, int sample_rate, void *stream) {
+    if (n == 0) return WH_OK;
+    if (!d_iq || !d_out || sample_rate <= 0) return set_err(WH_E_ARG, "wh_nco_mix: bad args");
+    if (n > (size_t)1 << 24) return set_err(WH_E_ARG, "wh_nco_mix: n > 2^24 (float32 ramp is not exact beyond)");
+    if (offset_hz == 0) {
+        if (d_out != d_iq)
+            WH_HIP(hipMemcpyAsync(d_out, d_iq, n * sizeof(float2), hipMemcpyDeviceToDevice, as_stream(stream)));
+        return WH_OK;
+    }
+    hipLaunchKernelGGL(nco_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float2 *>(d_iq), reinterpret_cast<float2 *>(d_out), n,
+                       nco_const(offset_hz, sample_rate));
+    WH_LAUNCH_CHECK();
+    return WH_OK;
+}
+
+extern "C" int wh_fm_discriminate(const float *d_iq, float *d_out, size_t n, int sample_rate, void *stream) {
+    if (n == 0) return WH_OK;
+    if (!d_iq || !d_out) return set_err(WH_E_ARG, "wh_fm_discriminate: null buffer");
+    float scale = (float)((double)sample_rate / (2.0 * M_PI * 75000.0));
+    hipLaunchKernelGGL(disc_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float2 *>(d_iq), d_out, n, scale);
+    WH_LAUNCH_CHECK();
+    return WH_OK;
+}
+
+struct wh_resampler {
+    double *d_taps = nullptr;
+    int ntaps, up, down, d0;
+};
+
+extern "C" int wh_resampler_create(wh_resampler **out, const double *h_taps, int ntaps, int up, int down, int d0) {
+    if (!out || !h_taps || ntaps < 1 || up < 1 || down < 1) return set_err(WH_E_ARG, "wh_resampler_create: bad args");
+    wh_resampler *r = new wh_resampler();
+    r->ntaps = ntaps; r->up = up; r->down = down; r->d0 = d0;
+    WH_HIP(hipMalloc(&r->d_taps, (size_t)ntaps * sizeof(double)));
+    WH_HIP(hipMemcpy(r->d_taps, h_taps, (size_t)ntaps * sizeof(double), hipMemcpyHostToDevice));
+    *out = r;
+    return WH_OK;
+}
+
+extern "C" void wh_resampler_destroy(wh_resampler *r) {
+    if (!r) return;
+    (void)hipFree(r->d_taps);
+    delete r;
+}
+
+static int launch_resample(const float *d_x, size_t n_in, size_t batch, float *d_y, size_t n_out, const double *taps,
+                           int ntaps, int up, int down, int d0, hipStream_t st) {
+    if (batch == 0 || n_out == 0) return WH_OK;
+    for (size_t b0 = 0; b0 < batch; b0 += 65535) {
+        size_t nb = batch - b0 < 65535 ? batch - b0 : 65535;
+        hipLaunchKernelGGL(resample_kernel, dim3((unsigned)((n_out + 3) / 4), (unsigned)nb), dim3(256), 0, st,
+                           d_x + b0 * n_in, n_in, d_y + b0 * n_out, n_out, taps, ntaps, up, down, d0);
+        WH_LAUNCH_CHECK();
+    }
+    return WH_OK;
+}
+
+extern "C" int wh_resampler_run(wh_resampler *r, const float *d_x, size_t n_in, size_t batch, float *d_y,
+                                size_t n_out, void *stream) {
+    if (!r || !d_x || !d_y) return set_err(WH_E_ARG, "wh_resampler_run: null");
+    return launch_resample(d_x, n_in, batch, d_y, n_out, r->d_taps, r->ntaps, r->up, r->down, r->d0, as_stream(stream));
+}
+
+struct wh_fmbank {
+    wh_fmbank_cfg cfg;
+    float *d_nco = nullptr;
+    double *d_taps = nullptr;
+    double *d_ba = nullptr;
+    double *d_acc = nullptr;
+    float *d_fm = nullptr;
+    size_t cap_chunks = 0;
+    bool fused = false;
+    int TO = 128;
+    size_t smem = 0;
+};
+
+extern "C" int wh_fmbank_create(wh_fmbank **out, const wh_fmbank_cfg *c) {
+    if (!out || !c || !c->h_offsets_hz || !c->h_taps) return set_err(WH_E_ARG, "wh_fmbank_create: null");
+    if (c->n_channels < 1 || c->n_channels > 65535 || c->chunk_len < 2 || c->chunk_len > (1 << 24) || c->ntaps < 1 ||
+        c->up < 1 || c->down < 1 || c->n_out < 1 || (c->mode != 0 && c->mode != 1) ||
+        (c->input_format != 0 && c->input_format != 1))
+        return set_err(WH_E_ARG, "wh_fmbank_create: bad configuration");
+    wh_fmbank *b = new wh_fmbank();
+    b->cfg = *c;
+    b->cfg.h_offsets_hz = nullptr;
+    b->cfg.h_taps = nullptr;
+    std::vector<float> nco(c->n_channels);
+    for (int k = 0; k < c->n_channels; ++k) nco[k] = c->h_offsets_hz[k] == 0 ? 0.0f : nco_const(c->h_offsets_hz[k], c->sample_rate);
+    WH_HIP(hipMalloc(&b->d_nco, nco.size() * sizeof(float)));
+    WH_HIP(hipMemcpy(b->d_nco, nco.data(), nco.size() * sizeof(float), hipMemcpyHostToDevice));
+    WH_HIP(hipMalloc(&b->d_taps, (size_t)c->ntaps * sizeof(double)));
+    WH_HIP(hipMemcpy(b->d_taps, c->h_taps, (size_t)c->ntaps * sizeof(double), hipMemcpyHostToDevice));
+    if (c->mode == 1 && c->h_mpx_b && c->h_mpx_a) {
+        double ba[12];
+        for (int i = 0; i < 6; ++i) {
+            ba[i] = c->h_mpx_b[i] / c->h_mpx_a[0];
+            ba[6 + i] = c->h_mpx_a[i] / c->h_mpx_a[0];
+        }
+        WH_HIP(hipMalloc(&b->d_ba, sizeof(ba)));
+        WH_HIP(hipMemcpy(b->d_ba, ba, sizeof(ba), hipMemcpyHostToDevice));
+    }
+    // fused path: nbfm, pure decimation, everything fits in LDS
+    b->fused = false;
+    if (c->mode == 0 && c->up == 1 && c->ntaps <= FM_MAX_TAPS) {
+        int TO = 256;
+        while (TO > 8 && c->ntaps + (TO - 1) * c->down > FM_MAX_SPAN) TO >>= 1;
+        if (c->ntaps + (TO - 1) * c->down <= FM_MAX_SPAN) {
+            b->fused = true;
+            b->TO = TO;
+            b->smem = (size_t)c->ntaps * sizeof(double) + (size_t)(c->ntaps + (TO - 1) * c->down) * sizeof(float);
+            WH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fmbank_fused_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->smem));
+        }
+    }
+    *out = b;
+    return WH_OK;
+}
+
+extern "C" void wh_fmbank_destroy(wh_fmbank *b) {
+    if (!b) return;
+    (void)hipFree(b->d_nco);
+    (void)hipFree(b->d_taps);
+    (void)hipFree(b->d_ba);
+    (void)hipFree(b->d_acc);
+    (void)hipFree(b->d_fm);
+    delete b;
+}
+
+extern "C" size_t wh_fmbank_workspace_bytes(const wh_fmbank *b, size_t n_chunks) {
+    if (!b) return 0;
+    size_t rows = n_chunks * (size_t)b->cfg.n_channels;
+    size_t bytes = rows * 2 * sizeof(double);
+    if (!b->fused) bytes += rows * (size_t)b->cfg.chunk_len * sizeof(float);
+    return bytes;
+}
+
+extern "C" int wh_fmbank_run(wh_fmbank *b, const void *d_in, size_t n_chunks, float *d_audio, float *d_metrics,
+                             void *stream) {
+    if (!b) return set_err(WH_E_ARG, "wh_fmbank_run: null handle");
+    if (n_chunks == 0) return WH_OK;
+    if (!d_in || !d_audio || !d_metrics) return set_err(WH_E_ARG, "wh_fmbank_run: null buffer");
+    if (n_chunks > 65535) return set_err(WH_E_ARG, "wh_fmbank_run: n_chunks > 65535 per call");
+    hipStream_t st = as_stream(stream);
+    const wh_fmbank_cfg &c = b->cfg;
+    const size_t rows = n_chunks * (size_t)c.n_channels;
+    if (n_chunks > b->cap_chunks) {  // grow the workspace (synchronises; steady state never does)
+        WH_HIP(hipStreamSynchronize(st));
+        (void)hipFree(b->d_acc);
+        (void)hipFree(b->d_fm);
+        b->d_acc = nullptr;
+        b->d_fm = nullptr;
+        WH_HIP(hipMalloc(&b->d_acc, rows * 2 * sizeof(double)));
+        if (!b->fused) WH_HIP(hipMalloc(&b->d_fm, rows * (size_t)c.chunk_len * sizeof(float)));
+        b->cap_chunks = n_chunks;
+    }
+    WH_HIP(hipMemsetAsync(b->d_acc, 0, rows * 2 * sizeof(double), st));
+    FmArgs a;
+    a.in = d_in;
+    a.audio = d_audio;
+    a.acc = b->d_acc;
+    a.fm_out = b->d_fm;
+    a.nco_c = b->d_nco;
+    a.taps = b->d_taps;
+    a.fmt = c.input_format;
+    a.N = c.chunk_len;
+    a.K = c.n_channels;
+    a.n_out = c.n_out;
+    a.ntaps = c.ntaps;
+    a.down = c.down;
+    a.d0 = c.d0;
+    a.TO = b->TO;
+    a.scale = (float)((double)c.sample_rate / (2.0 * M_PI * 75000.0));
+    if (b->fused) {
+        int tiles = (c.n_out + b->TO - 1) / b->TO;
+        hipLaunchKernelGGL(fmbank_fused_kernel, dim3(tiles, c.n_channels, (unsigned)n_chunks), dim3(256), b->smem, st, a);
+        WH_LAUNCH_CHECK();
+    } else {
+        int per_block = 4 * 63 * 16;
+        int blocks = (c.chunk_len + per_block - 1) / per_block;
+        hipLaunchKernelGGL(fmbank_disc_kernel, dim3(blocks, c.n_channels, (unsigned)n_chunks), dim3(256), 0, st, a);
+        WH_LAUNCH_CHECK();
+        if (c.mode == 1) {
+            // float32 coefficient arrays of the reference: b=[alpha], a=[1, -(1-alpha)] (dsp/fm.py:106-107)
+            hipLaunchKernelGGL(wbfm_iir_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st, b->d_fm, b->d_acc,
+                               (int)rows, c.chunk_len, c.deemph_b0, -c.deemph_a1, b->d_ba, b->d_ba ? 1 : 0);
+            WH_LAUNCH_CHECK();
+        }
+        int rc = launch_resample(b->d_fm, (size_t)c.chunk_len, rows, d_audio, (size_t)c.n_out, b->d_taps, c.ntaps, c.up,
+                                 c.down, c.d0, st);
+        if (rc != WH_OK) return rc;
+    }
+    hipLaunchKernelGGL(fmbank_finalize_kernel, dim3((unsigned)rows), dim3(256), 0, st, d_audio, b->d_acc, d_metrics,
+                       c.chunk_len, c.n_out);
+    WH_LAUNCH_CHECK();
+    return WH_OK;
+}

@@ -1,0 +1,551 @@
+// 2x-oversampled polyphase filterbank (reference dsp/channelizer.py:28-158) for gfx950.
+//
+// Math (reference quirks kept):  block_g[k] = x[g*M/2 + k], k in [0,M);
+//   y_h[k] = sum_{j<T} block_{h-j}[k] * arms[k][j]      (block_g for g<0 = carried history col -g-1)
+//   out[h][c] = sum_k y_h[k] * exp(-2 pi i k c / M)     (forward, unnormalised)
+//
+// Fast path (M = 1024, T = 9): one fused kernel, HBM traffic = read x once (+halo) and write
+// out once = 24 B per input sample.  A 256-thread workgroup walks a run of consecutive hops.
+//   * arm MAC: thread t owns columns k0 = t and t+256 of the half-block; because block_g[k0+512]
+//     == block_{g+1}[k0], one sliding register window c_g = x[g*512+k0] serves both halves, so
+//     every input sample is loaded once per workgroup (coalesced 8 B/lane) and the 36 tap
+//     values live in registers -- no LDS in this phase.
+//   * FFT-1024 = 4 x 16 x 16: the radix-4 stage needs y[t], y[t+256], y[t+512], y[t+768], which
+//     is exactly what thread t holds -> done in registers; then two radix-16 stages with one wave
+//     per hop (4 hops in flight per workgroup), exchanging through padded LDS images
+//     (conflict-free ds_write_b64 / ds_read_b64 / ds_read_b128).
+// Generic path (any even M): one workgroup per hop, MAC into LDS, then LDS radix-2 FFT (M power of
+// two) or direct DFT (otherwise).  Also used for the first T-1 hops of a call (history) and the
+// tail hops of the fast path.
+#include "wh_common.h"
+#include <cmath>
+#include <vector>
+
+using namespace wh;
+
+namespace {
+
+constexpr int FM = 1024;       // fast-path channel count
+constexpr int FHOP = 512;
+constexpr int FT = 9;
+constexpr int GH = 4;          // hops per group (= waves per workgroup)
+constexpr int LDS1_K1 = 272;   // stage-1 image: idx = k1*272 + n2*16 + n3   (complex units)
+constexpr int LDS2_ROW = 18;   // stage-2 image: idx = (k2*4 + k1)*18 + n3
+constexpr int LDS_HOP = 1152;  // complex per hop image (max(4*272, 64*18))
+
+struct PfbFastArgs {
+    const float2 *x;        // input samples
+    float2 *out;            // [hops][1024]
+    const float *arms;      // float32 [1024][9]
+    const float2 *tw1024;   // exp(-2 pi i m/1024)
+    long long first_hop;    // first hop handled by the fast kernel (>= 8)
+    long long n_groups;     // total groups of GH hops
+    int groups_per_wg;
+    int n_wg;
+};
+
+__global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
+    __shared__ __attribute__((aligned(16))) float2 lds[GH * LDS_HOP + 256];
+    float2 *tw256 = lds + GH * LDS_HOP;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = t >> 6;
+
+    // XCD-aware run mapping: blocks b and b+8 share an XCD (round-robin dispatch); give each
+    // XCD a contiguous range of runs so that the 9-block halo of neighbouring runs hits its L2.
+    int b = blockIdx.x;
+    int nwg = a.n_wg;
+    int per = nwg >> 3;
+    int run = (nwg & 7) == 0 ? (b & 7) * per + (b >> 3) : b;
+
+    long long g0 = (long long)run * a.groups_per_wg;
+    long long g1 = g0 + a.groups_per_wg;
+    if (g1 > a.n_groups) g1 = a.n_groups;
+    if (g0 >= g1) return;
+
+    // taps: arms[k][j] for k = t, t+256, t+512, t+768
+    float tap[4][FT];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < FT; ++j) tap[q][j] = a.arms[(t + 256 * q) * FT + j];
+
+    // stage-1 twiddles W1024^(t*k1), k1 = 1..3
+    float2 tw1 = a.tw1024[t], tw2 = a.tw1024[(2 * t) & 1023], tw3 = a.tw1024[(3 * t) & 1023];
+    tw256[t] = a.tw1024[4 * t];
+
+    long long h = a.first_hop + g0 * GH;  // first hop of this run
+    // windows: wA[i] = x[(h-8+i)*512 + t], wB[i] = x[(h-8+i)*512 + t + 256], i = 0..8 carried,
+    // i = 9..12 filled per group
+    float2 wA[9 + GH], wB[9 + GH];
+    const float2 *xp = a.x + (h - 8) * FHOP + t;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        wA[i] = xp[i * FHOP];
+        wB[i] = xp[i * FHOP + 256];
+    }
+    // prefetch the first group's new samples
+    float2 nA[GH], nB[GH];
+#pragma unroll
+    for (int i = 0; i < GH; ++i) {
+        nA[i] = xp[(9 + i) * FHOP];
+        nB[i] = xp[(9 + i) * FHOP + 256];
+    }
+    __syncthreads();  // tw256 visible
+
+    for (long long g = g0; g < g1; ++g, h += GH) {
+#pragma unroll
+        for (int i = 0; i < GH; ++i) {
+            wA[9 + i] = nA[i];
+            wB[9 + i] = nB[i];
+        }
+        // prefetch next group (clamped to the last group: harmless duplicate loads)
+        {
+            long long hn = (g + 1 < g1) ? h + GH : h;
+            const float2 *xn = a.x + (hn + 1) * FHOP + t;
+#pragma unroll
+            for (int i = 0; i < GH; ++i) {
+                nA[i] = xn[i * FHOP];
+                nB[i] = xn[i * FHOP + 256];
+            }
+        }
+        // ---- arm MAC + radix-4 stage for GH hops --------------------------------------------
+#pragma unroll
+        for (int i = 0; i < GH; ++i) {
+            // hop h+i: y[k0] uses c_{h+i-j} = w[i+8-j]; y[k0+512] uses c_{h+i-j+1} = w[i+9-j]
+            float2 y0 = make_float2(0.f, 0.f), y1 = y0, y2 = y0, y3 = y0;
+#pragma unroll
+            for (int j = 0; j < FT; ++j) {
+                float2 ca = wA[i + 8 - j], cb = wB[i + 8 - j];
+                float2 ca1 = wA[i + 9 - j], cb1 = wB[i + 9 - j];
+                y0.x = fmaf(ca.x, tap[0][j], y0.x);
+                y0.y = fmaf(ca.y, tap[0][j], y0.y);   // k = t
+                y1.x = fmaf(cb.x, tap[1][j], y1.x);
+                y1.y = fmaf(cb.y, tap[1][j], y1.y);   // k = t+256
+                y2.x = fmaf(ca1.x, tap[2][j], y2.x);
+                y2.y = fmaf(ca1.y, tap[2][j], y2.y);  // k = t+512
+                y3.x = fmaf(cb1.x, tap[3][j], y3.x);
+                y3.y = fmaf(cb1.y, tap[3][j], y3.y);  // k = t+768
+            }
+            fft4(y0, y1, y2, y3);  // A[k1], n1 = k/256
+            y1 = cmul(y1, tw1);
+            y2 = cmul(y2, tw2);
+            y3 = cmul(y3, tw3);
+            float2 *L = lds + i * LDS_HOP;
+            L[t] = y0;
+            L[LDS1_K1 + t] = y1;
+            L[2 * LDS1_K1 + t] = y2;
+            L[3 * LDS1_K1 + t] = y3;
+        }
+        // slide the windows
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            wA[i] = wA[i + GH];
+            wB[i] = wB[i + GH];
+        }
+        __syncthreads();
+        // ---- stage 2 (radix-16 over n2) : wave = hop, lane = (k1, n3) ------------------------
+        {
+            float2 *L = lds + wave * LDS_HOP;
+            const int k1 = lane >> 4, n3 = lane & 15;
+            float2 v[16];
+            const float2 *src = L + k1 * LDS1_K1 + n3;
+#pragma unroll
+            for (int n2 = 0; n2 < 16; ++n2) v[n2] = src[n2 * 16];
+            fft16(v);
+            // twiddle W256^(n3*k2) and store to image 2 (same wave only: no barrier needed,
+            // every lane's reads above were issued before these writes)
+            __builtin_amdgcn_wave_barrier();
+            float2 *dst = L + k1 * LDS2_ROW + n3;
+            dst[0] = v[0];
+#pragma unroll
+            for (int k2 = 1; k2 < 16; ++k2) {
+                float2 w = tw256[(n3 * k2) & 255];
+                dst[k2 * 4 * LDS2_ROW] = cmul(v[k2], w);
+            }
+        }
+        // ---- stage 3 (radix-16 over n3) : lane = k1 + 4*k2, row = lane ------------------------
+        __builtin_amdgcn_wave_barrier();
+        {
+            float2 *L = lds + wave * LDS_HOP;
+            float2 v[16];
+            const float4 *src = reinterpret_cast<const float4 *>(L + lane * LDS2_ROW);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                float4 p = src[q];
+                v[2 * q] = make_float2(p.x, p.y);
+                v[2 * q + 1] = make_float2(p.z, p.w);
+            }
+            fft16(v);
+            float2 *o = a.out + (h + wave) * FM + lane;  // k = lane + 64*k3
+#pragma unroll
+            for (int k3 = 0; k3 < 16; ++k3) o[64 * k3] = v[k3];
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// generic path: one workgroup per hop
+// ------------------------------------------------------------------------------------------
+struct PfbGenArgs {
+    const float2 *x;
+    const float2 *hist;  // [M][T] carried history (column j = block_{-1-j})
+    float2 *out;
+    const float *arms;   // float32 [M][T]
+    const float2 *tw;    // exp(-2 pi i m / M), m in [0, M)
+    int M, T, log2M;     // log2M = 0 when M is not a power of two
+    long long hop0;      // first hop handled
+    long long n_hops;    // hops handled (grid.x)
+};
+
+__device__ __forceinline__ float2 gen_block(const PfbGenArgs &a, long long g, int k) {
+    if (g >= 0) return a.x[g * (a.M / 2) + k];
+    int col = (int)(-g - 1);
+    if (col >= a.T) return make_float2(0.f, 0.f);
+    return a.hist[(size_t)k * a.T + col];
+}
+
+__global__ __launch_bounds__(256) void pfb_generic_kernel(PfbGenArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float2 sm[];  // M complex (+M for pow2 ping-pong)
+    const long long h = a.hop0 + blockIdx.x;
+    const int M = a.M, T = a.T;
+    for (int k = threadIdx.x; k < M; k += blockDim.x) {
+        float re = 0.f, im = 0.f;
+        for (int j = 0; j < T; ++j) {
+            float2 c = gen_block(a, h - j, k);
+            float w = a.arms[(size_t)k * T + j];
+            re = fmaf(c.x, w, re);
+            im = fmaf(c.y, w, im);
+        }
+        sm[k] = make_float2(re, im);
+    }
+    __syncthreads();
+    float2 *o = a.out + (size_t)h * M;
+    if (a.log2M > 0) {
+        // Stockham autosort radix-2 (DIF), ping-pong between sm[0:M) and sm[M:2M):
+        // stage with sub-length n and stride s (n*s = M): for p < n/2, q < s
+        //   y[q + s*2p] = a + b ; y[q + s*(2p+1)] = (a - b) * exp(-2 pi i p/n)
+        float2 *src = sm, *dst = sm + M;
+        const int half = M >> 1;
+        int n = M, s = 1;
+        for (int st = 0; st < a.log2M; ++st) {
+            const int m = n >> 1;
+            for (int i = threadIdx.x; i < half; i += blockDim.x) {
+                int pp = i / s, q = i - pp * s;
+                float2 c0 = src[q + s * pp];
+                float2 c1 = src[q + s * (pp + m)];
+                float2 w = a.tw[(size_t)pp * s];
+                dst[q + s * 2 * pp] = cadd(c0, c1);
+                dst[q + s * (2 * pp + 1)] = cmul(csub(c0, c1), w);
+            }
+            __syncthreads();
+            float2 *tmp = src; src = dst; dst = tmp;
+            n = m; s <<= 1;
+        }
+        for (int k = threadIdx.x; k < M; k += blockDim.x) o[k] = src[k];
+    } else {
+        for (int c = threadIdx.x; c < M; c += blockDim.x) {
+            float re = 0.f, im = 0.f;
+            int idx = 0;
+            for (int k = 0; k < M; ++k) {
+                float2 y = sm[k];
+                float2 w = a.tw[idx];
+                re += y.x * w.x - y.y * w.y;
+                im += y.x * w.y + y.y * w.x;
+                idx += c;
+                if (idx >= M) idx -= M;
+            }
+            o[c] = make_float2(re, im);
+        }
+    }
+}
+
+// new_hist[k][j] = block_{H-1-j}[k]
+__global__ void pfb_hist_kernel(const float2 *x, const float2 *old_hist, float2 *new_hist, int M, int T,
+                                long long H) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= M * T) return;
+    int k = idx / T, j = idx % T;
+    long long g = H - 1 - j;
+    float2 v;
+    if (g >= 0) v = x[g * (M / 2) + k];
+    else {
+        int col = (int)(-g - 1);
+        v = col < T ? old_hist[(size_t)k * T + col] : make_float2(0.f, 0.f);
+    }
+    new_hist[idx] = v;
+}
+
+__global__ void extract_channel_kernel(const float2 *out, size_t hops, int M, int idx, float2 *col) {
+    size_t h = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (h < hops) col[h] = out[h * M + idx];
+}
+
+// per-channel activity statistics: grid.x = ceil(M/64), grid.y = hop slices; block (64, 4)
+__global__ void pfb_stats_kernel(const float2 *out, size_t hops, int M, double *part /*[slices][M][4]*/,
+                                 int slices) {
+    int c = blockIdx.x * 64 + threadIdx.x;
+    int sl = blockIdx.y;
+    size_t per = (hops + slices - 1) / slices;
+    size_t h0 = (size_t)sl * per, h1 = h0 + per < hops ? h0 + per : hops;
+    double s = 0, s2 = 0, mn = 1e300, mx = -1e300;
+    if (c < M) {
+        for (size_t h = h0 + threadIdx.y; h < h1; h += blockDim.y) {
+            float2 v = out[h * M + c];
+            double p = (double)v.x * v.x + (double)v.y * v.y;
+            s += p; s2 += p * p;
+            mn = p < mn ? p : mn;
+            mx = p > mx ? p : mx;
+        }
+    }
+    __shared__ double red[4][4][64];
+    red[0][threadIdx.y][threadIdx.x] = s;
+    red[1][threadIdx.y][threadIdx.x] = s2;
+    red[2][threadIdx.y][threadIdx.x] = mn;
+    red[3][threadIdx.y][threadIdx.x] = mx;
+    __syncthreads();
+    if (threadIdx.y == 0 && c < M) {
+        for (int y = 1; y < 4; ++y) {
+            s += red[0][y][threadIdx.x];
+            s2 += red[1][y][threadIdx.x];
+            mn = fmin(mn, red[2][y][threadIdx.x]);
+            mx = fmax(mx, red[3][y][threadIdx.x]);
+        }
+        double *p = part + ((size_t)sl * M + c) * 4;
+        p[0] = s; p[1] = s2; p[2] = mn; p[3] = mx;
+    }
+}
+
+__global__ void pfb_stats_final_kernel(const double *part, int slices, int M, size_t hops, double *stats,
+                                       int accumulate) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= M) return;
+    double s = 0, s2 = 0, mn = 1e300, mx = -1e300;
+    for (int sl = 0; sl < slices; ++sl) {
+        const double *p = part + ((size_t)sl * M + c) * 4;
+        s += p[0]; s2 += p[1];
+        mn = fmin(mn, p[2]);
+        mx = fmax(mx, p[3]);
+    }
+    double *o = stats + (size_t)c * 5;
+    if (accumulate) {
+        o[0] += s; o[1] += s2; o[2] += (double)hops;
+        o[3] = fmin(o[3], mn); o[4] = fmax(o[4], mx);
+    } else {
+        o[0] = s; o[1] = s2; o[2] = (double)hops; o[3] = mn; o[4] = mx;
+    }
+}
+
+}  // namespace
+
+struct wh_pfb {
+    int M, T, log2M;
+    float *d_arms = nullptr;    // [M][T] float32
+    float2 *d_tw = nullptr;     // [M]
+    float2 *d_hist[2] = {nullptr, nullptr};
+    int cur = 0;
+    double *d_part = nullptr;   // stats partials
+    int cu_count = 256;
+    bool prof = false;          // bracket the fused kernel with events (bench roofline)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_valid = false;
+};
+
+extern "C" int wh_pfb_create(wh_pfb **out, int M, int T, const double *h_arms) {
+    if (!out || !h_arms || M < 2 || (M & 1) || T < 1 || T > 64) return set_err(WH_E_ARG, "wh_pfb_create: bad M/T");
+    if ((size_t)M * 16 > 160 * 1024) return set_err(WH_E_ARG, "wh_pfb_create: M=%d exceeds the LDS-resident limit", M);
+    wh_pfb *p = new wh_pfb();
+    p->M = M; p->T = T;
+    int l2 = 0;
+    while ((1 << l2) < M) ++l2;
+    p->log2M = ((1 << l2) == M) ? l2 : 0;
+    std::vector<float> arms((size_t)M * T);
+    for (size_t i = 0; i < arms.size(); ++i) arms[i] = (float)h_arms[i];
+    std::vector<float2> tw(M);
+    for (int m = 0; m < M; ++m) {
+        double ang = -2.0 * M_PI * (double)m / (double)M;
+        tw[m] = make_float2((float)cos(ang), (float)sin(ang));
+    }
+    hipDeviceProp_t prop;
+    int dev = 0;
+    WH_HIP(hipGetDevice(&dev));
+    WH_HIP(hipGetDeviceProperties(&prop, dev));
+    p->cu_count = prop.multiProcessorCount;
+    WH_HIP(hipMalloc(&p->d_arms, arms.size() * sizeof(float)));
+    WH_HIP(hipMalloc(&p->d_tw, tw.size() * sizeof(float2)));
+    WH_HIP(hipMalloc(&p->d_hist[0], (size_t)M * T * sizeof(float2)));
+    WH_HIP(hipMalloc(&p->d_hist[1], (size_t)M * T * sizeof(float2)));
+    WH_HIP(hipMalloc(&p->d_part, (size_t)64 * M * 4 * sizeof(double)));
+    WH_HIP(hipMemcpy(p->d_arms, arms.data(), arms.size() * sizeof(float), hipMemcpyHostToDevice));
+    WH_HIP(hipMemcpy(p->d_tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice));
+    WH_HIP(hipMemset(p->d_hist[0], 0, (size_t)M * T * sizeof(float2)));
+    WH_HIP(hipMemset(p->d_hist[1], 0, (size_t)M * T * sizeof(float2)));
+    *out = p;
+    return WH_OK;
+}
+
+extern "C" void wh_pfb_destroy(wh_pfb *p) {
+    if (!p) return;
+    (void)hipFree(p->d_arms);
+    (void)hipFree(p->d_tw);
+    (void)hipFree(p->d_hist[0]);
+    (void)hipFree(p->d_hist[1]);
+    (void)hipFree(p->d_part);
+    if (p->ev0) (void)hipEventDestroy(p->ev0);
+    if (p->ev1) (void)hipEventDestroy(p->ev1);
+    delete p;
+}
+
+extern "C" int wh_pfb_profile(wh_pfb *p, int enable) {
+    if (!p) return set_err(WH_E_ARG, "wh_pfb_profile: null handle");
+    if (enable && !p->ev0) {
+        WH_HIP(hipEventCreate(&p->ev0));
+        WH_HIP(hipEventCreate(&p->ev1));
+    }
+    p->prof = enable != 0;
+    p->ev_valid = false;
+    return WH_OK;
+}
+
+extern "C" int wh_pfb_kernel_ms(wh_pfb *p, float *ms) {
+    if (!p || !ms) return set_err(WH_E_ARG, "wh_pfb_kernel_ms: null");
+    if (!p->ev_valid) return set_err(WH_E_ARG, "wh_pfb_kernel_ms: no profiled fused-kernel launch yet");
+    WH_HIP(hipEventSynchronize(p->ev1));
+    WH_HIP(hipEventElapsedTime(ms, p->ev0, p->ev1));
+    return WH_OK;
+}
+
+extern "C" size_t wh_pfb_hops(const wh_pfb *p, size_t n) {
+    if (!p || n < (size_t)p->M) return 0;
+    return (n - p->M) / (p->M / 2) + 1;
+}
+
+static int launch_generic(wh_pfb *p, const float *d_iq, float *d_out, long long hop0, long long n_hops,
+                          hipStream_t st) {
+    if (n_hops <= 0) return WH_OK;
+    PfbGenArgs a;
+    a.x = reinterpret_cast<const float2 *>(d_iq);
+    a.hist = p->d_hist[p->cur];
+    a.out = reinterpret_cast<float2 *>(d_out);
+    a.arms = p->d_arms;
+    a.tw = p->d_tw;
+    a.M = p->M; a.T = p->T; a.log2M = p->log2M;
+    a.hop0 = hop0; a.n_hops = n_hops;
+    size_t smem = (size_t)p->M * sizeof(float2) * (p->log2M ? 2 : 1);
+    if (smem > 64 * 1024) {
+        WH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pfb_generic_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    }
+    // grid.x is limited to 2^31-1; chunk very long tails (never happens for the fast path)
+    const long long MAXG = 1 << 30;
+    for (long long off = 0; off < n_hops; off += MAXG) {
+        long long cnt = n_hops - off < MAXG ? n_hops - off : MAXG;
+        a.hop0 = hop0 + off;
+        a.n_hops = cnt;
+        hipLaunchKernelGGL(pfb_generic_kernel, dim3((unsigned)cnt), dim3(256), smem, st, a);
+        WH_LAUNCH_CHECK();
+    }
+    return WH_OK;
+}
+
+extern "C" int wh_pfb_run(wh_pfb *p, const float *d_iq, size_t n, float *d_out, void *stream) {
+    if (!p) return set_err(WH_E_ARG, "wh_pfb_run: null handle");
+    hipStream_t st = as_stream(stream);
+    long long H = (long long)wh_pfb_hops(p, n);
+    if (H == 0) return WH_OK;
+    if (!d_iq || !d_out) return set_err(WH_E_ARG, "wh_pfb_run: null buffer");
+    int rc;
+    const bool fast = (p->M == FM && p->T == FT);
+    long long head = fast ? (H < 8 ? H : 8) : H;
+    if ((rc = launch_generic(p, d_iq, d_out, 0, head, st)) != WH_OK) return rc;
+    if (fast && H > 8) {
+        long long n_groups = (H - 8) / GH;
+        if (n_groups > 0) {
+            PfbFastArgs a;
+            a.x = reinterpret_cast<const float2 *>(d_iq);
+            a.out = reinterpret_cast<float2 *>(d_out);
+            a.arms = p->d_arms;
+            a.tw1024 = p->d_tw;
+            a.first_hop = 8;
+            a.n_groups = n_groups;
+            // runs of ~64 hops, but at least ~8 workgroups per CU when the input allows
+            int gpw = 16;
+            long long nwg = (n_groups + gpw - 1) / gpw;
+            while (gpw > 2 && nwg < (long long)p->cu_count * 8) {
+                gpw >>= 1;
+                nwg = (n_groups + gpw - 1) / gpw;
+            }
+            a.groups_per_wg = gpw;
+            a.n_wg = (int)nwg;
+            if (p->prof) WH_HIP(hipEventRecord(p->ev0, st));
+            hipLaunchKernelGGL(pfb1024_kernel, dim3((unsigned)nwg), dim3(256), 0, st, a);
+            WH_LAUNCH_CHECK();
+            if (p->prof) {
+                WH_HIP(hipEventRecord(p->ev1, st));
+                p->ev_valid = true;
+            }
+        }
+        long long done = 8 + n_groups * GH;
+        if ((rc = launch_generic(p, d_iq, d_out, done, H - done, st)) != WH_OK) return rc;
+    }
+    // carry the history
+    int nxt = p->cur ^ 1;
+    int tot = p->M * p->T;
+    hipLaunchKernelGGL(pfb_hist_kernel, dim3((tot + 255) / 256), dim3(256), 0, st,
+                       reinterpret_cast<const float2 *>(d_iq), p->d_hist[p->cur], p->d_hist[nxt], p->M, p->T, H);
+    WH_LAUNCH_CHECK();
+    p->cur = nxt;
+    return WH_OK;
+}
+
+extern "C" int wh_pfb_reset(wh_pfb *p, void *stream) {
+    if (!p) return set_err(WH_E_ARG, "wh_pfb_reset: null handle");
+    WH_HIP(hipMemsetAsync(p->d_hist[p->cur], 0, (size_t)p->M * p->T * sizeof(float2), as_stream(stream)));
+    return WH_OK;
+}
+
+extern "C" int wh_pfb_get_history(wh_pfb *p, float *h_hist, void *stream) {
+    if (!p || !h_hist) return set_err(WH_E_ARG, "wh_pfb_get_history: null");
+    WH_HIP(hipMemcpyAsync(h_hist, p->d_hist[p->cur], (size_t)p->M * p->T * sizeof(float2), hipMemcpyDeviceToHost,
+                          as_stream(stream)));
+    WH_HIP(hipStreamSynchronize(as_stream(stream)));
+    return WH_OK;
+}
+
+extern "C" int wh_pfb_set_history(wh_pfb *p, const float *h_hist, void *stream) {
+    if (!p || !h_hist) return set_err(WH_E_ARG, "wh_pfb_set_history: null");
+    WH_HIP(hipMemcpyAsync(p->d_hist[p->cur], h_hist, (size_t)p->M * p->T * sizeof(float2), hipMemcpyHostToDevice,
+                          as_stream(stream)));
+    WH_HIP(hipStreamSynchronize(as_stream(stream)));
+    return WH_OK;
+}
+
+extern "C" int wh_pfb_extract_channel(const float *d_out, size_t hops, int M, int idx, float *d_col, void *stream) {
+    if (hops == 0) return WH_OK;
+    if (!d_out || !d_col || idx < 0 || idx >= M) return set_err(WH_E_ARG, "wh_pfb_extract_channel: bad args");
+    hipLaunchKernelGGL(extract_channel_kernel, dim3((unsigned)((hops + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float2 *>(d_out), hops, M, idx, reinterpret_cast<float2 *>(d_col));
+    WH_LAUNCH_CHECK();
+    return WH_OK;
+}
+
+extern "C" int wh_pfb_channel_stats(const float *d_out, size_t hops, int M, double *d_stats, int accumulate,
+                                    void *stream) {
+    if (!d_out || !d_stats || M < 1) return set_err(WH_E_ARG, "wh_pfb_channel_stats: bad args");
+    if (hops == 0) return WH_OK;
+    hipStream_t st = as_stream(stream);
+    int slices = (int)((hops + 255) / 256);
+    if (slices > 64) slices = 64;
+    double *part = nullptr;
+    WH_HIP(hipMallocAsync(reinterpret_cast<void **>(&part), (size_t)slices * M * 4 * sizeof(double), st));
+    hipLaunchKernelGGL(pfb_stats_kernel, dim3((M + 63) / 64, slices), dim3(64, 4), 0, st,
+                       reinterpret_cast<const float2 *>(d_out), hops, M, part, slices);
+    WH_LAUNCH_CHECK();
+    hipLaunchKernelGGL(pfb_stats_final_kernel, dim3((M + 255) / 256), dim3(256), 0, st, part, slices, M, hops,
+                       d_stats, accumulate);
+    WH_LAUNCH_CHECK();
+    WH_HIP(hipFreeAsync(part, st));
+    return WH_OK;
+}

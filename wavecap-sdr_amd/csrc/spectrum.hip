@@ -1,0 +1,123 @@
+// Spectrum frames (reference dsp/fft/scipy_backend.py:38-79): Hann window -> FFT -> fftshift ->
+// 20 log10(|X| + 1e-10), fused in one kernel, one workgroup per frame (batched over frames).
+// FFT: LDS Stockham radix-2 for power-of-two sizes, direct DFT otherwise.
+#include "wh_common.h"
+#include <cmath>
+#include <vector>
+
+using namespace wh;
+
+namespace {
+
+__global__ __launch_bounds__(256) void spectrum_kernel(const float2 *iq, size_t frame_stride, float *out,
+                                                       const float *window, const float2 *tw, int N, int log2N) {
+    extern __shared__ __attribute__((aligned(16))) float2 sm[];
+    const float2 *x = iq + (size_t)blockIdx.x * frame_stride;
+    float *o = out + (size_t)blockIdx.x * N;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        float2 v = x[n];
+        float w = window[n];
+        sm[n] = make_float2(v.x * w, v.y * w);
+    }
+    __syncthreads();
+    const int shift = N - N / 2;  // fftshift: shifted[i] = X[(i + ceil(N/2)) mod N]
+    if (log2N > 0) {
+        float2 *src = sm, *dst = sm + N;
+        const int half = N >> 1;
+        int n = N, s = 1;
+        for (int st = 0; st < log2N; ++st) {
+            const int m = n >> 1;
+            for (int i = threadIdx.x; i < half; i += 256) {
+                int pp = i / s, q = i - pp * s;
+                float2 c0 = src[q + s * pp];
+                float2 c1 = src[q + s * (pp + m)];
+                float2 w = tw[(size_t)pp * s];
+                dst[q + s * 2 * pp] = cadd(c0, c1);
+                dst[q + s * (2 * pp + 1)] = cmul(csub(c0, c1), w);
+            }
+            __syncthreads();
+            float2 *tmp = src; src = dst; dst = tmp;
+            n = m; s <<= 1;
+        }
+        for (int i = threadIdx.x; i < N; i += 256) {
+            int k = i + shift;
+            if (k >= N) k -= N;
+            float2 X = src[k];
+            float mag = sqrtf(X.x * X.x + X.y * X.y) + 1e-10f;
+            o[i] = 20.0f * log10f(mag);
+        }
+    } else {
+        for (int i = threadIdx.x; i < N; i += 256) {
+            int k = i + shift;
+            if (k >= N) k -= N;
+            float re = 0.f, im = 0.f;
+            int idx = 0;
+            for (int n = 0; n < N; ++n) {
+                float2 y = sm[n];
+                float2 w = tw[idx];
+                re += y.x * w.x - y.y * w.y;
+                im += y.x * w.y + y.y * w.x;
+                idx += k;
+                if (idx >= N) idx -= N;
+            }
+            float mag = sqrtf(re * re + im * im) + 1e-10f;
+            o[i] = 20.0f * log10f(mag);
+        }
+    }
+}
+
+}  // namespace
+
+struct wh_spectrum {
+    int N, log2N;
+    float *d_window = nullptr;
+    float2 *d_tw = nullptr;
+    size_t smem = 0;
+};
+
+extern "C" int wh_spectrum_create(wh_spectrum **out, int N) {
+    if (!out || N < 2 || N > 16384) return set_err(WH_E_ARG, "wh_spectrum_create: fft_size must be in [2, 16384]");
+    wh_spectrum *s = new wh_spectrum();
+    s->N = N;
+    int l2 = 0;
+    while ((1 << l2) < N) ++l2;
+    s->log2N = ((1 << l2) == N && N <= 8192) ? l2 : 0;
+    std::vector<float> w(N);
+    for (int n = 0; n < N; ++n)  // np.hanning(N): 0.5 - 0.5 cos(2 pi n/(N-1)), float64 then cast
+        w[n] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * (double)n / (double)(N - 1)));
+    std::vector<float2> tw(N);
+    for (int m = 0; m < N; ++m) {
+        double ang = -2.0 * M_PI * (double)m / (double)N;
+        tw[m] = make_float2((float)cos(ang), (float)sin(ang));
+    }
+    WH_HIP(hipMalloc(&s->d_window, (size_t)N * sizeof(float)));
+    WH_HIP(hipMalloc(&s->d_tw, (size_t)N * sizeof(float2)));
+    WH_HIP(hipMemcpy(s->d_window, w.data(), (size_t)N * sizeof(float), hipMemcpyHostToDevice));
+    WH_HIP(hipMemcpy(s->d_tw, tw.data(), (size_t)N * sizeof(float2), hipMemcpyHostToDevice));
+    s->smem = (size_t)N * sizeof(float2) * (s->log2N ? 2 : 1);
+    if (s->smem > 64 * 1024)
+        WH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(spectrum_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->smem));
+    *out = s;
+    return WH_OK;
+}
+
+extern "C" void wh_spectrum_destroy(wh_spectrum *s) {
+    if (!s) return;
+    (void)hipFree(s->d_window);
+    (void)hipFree(s->d_tw);
+    delete s;
+}
+
+extern "C" int wh_spectrum_run(wh_spectrum *s, const float *d_iq, size_t n_frames, size_t frame_stride,
+                               float *d_power_db, void *stream) {
+    if (!s) return set_err(WH_E_ARG, "wh_spectrum_run: null handle");
+    if (n_frames == 0) return WH_OK;
+    if (!d_iq || !d_power_db) return set_err(WH_E_ARG, "wh_spectrum_run: null buffer");
+    if (n_frames > 0x7fffffff) return set_err(WH_E_ARG, "wh_spectrum_run: too many frames");
+    hipLaunchKernelGGL(spectrum_kernel, dim3((unsigned)n_frames), dim3(256), s->smem, as_stream(stream),
+                       reinterpret_cast<const float2 *>(d_iq), frame_stride, d_power_db, s->d_window, s->d_tw, s->N,
+                       s->log2N);
+    WH_LAUNCH_CHECK();
+    return WH_OK;
+}

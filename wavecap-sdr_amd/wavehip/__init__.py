@@ -1,0 +1,25 @@
+"""wavehip -- MI355X-native implementation of WaveCap-SDR's per-channel DSP hot path.
+
+Host-side mirror of the reference's operator surfaces (same names, arguments and
+error behaviour) over libwavehip.so (hand-written HIP for gfx950):
+
+    PolyphaseChannelizer      <- wavecapsdr/dsp/channelizer.py:28
+    HipFFTBackend             <- wavecapsdr/dsp/fft/base.py:31 (FFTBackend plugin)
+    process_channel_dsp_stateless / ChannelBank  <- wavecapsdr/capture.py:298
+    C4FMDemodulator / C4FMBank <- wavecapsdr/dsp/p25/c4fm.py:2379
+
+PyTorch-ROCm is used for device buffers and streams only.  There is no CPU
+fallback: without the built library (or without a GPU) the operators raise.
+"""
+
+from ._lib import LIB_PATH, lib  # noqa: F401  (raises ImportError if the .so is missing)
+from .channelizer import PolyphaseChannelizer, ChannelCalculator  # noqa: F401
+from .fft_backend import HipFFTBackend, FFTResult, FFTBackend, is_available, register_with  # noqa: F401
+from .channel_ops import ChannelBank, ChannelConfig, process_channel_dsp_stateless  # noqa: F401
+from .wire import pack_iq16, unpack_iq16, pack_pcm16  # noqa: F401
+
+__all__ = [
+    "PolyphaseChannelizer", "ChannelCalculator", "HipFFTBackend", "FFTResult", "FFTBackend", "is_available",
+    "register_with", "ChannelBank", "ChannelConfig", "process_channel_dsp_stateless", "pack_iq16", "unpack_iq16",
+    "pack_pcm16",
+]

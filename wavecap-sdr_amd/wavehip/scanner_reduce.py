@@ -1,0 +1,58 @@
+"""Cross-stream scanner / activity reduction.
+
+Each GPU owns one device stream and produces per-channel BinStats-style statistics
+{sum p, sum p^2, count, min p, max p} (channel_classifier.py:17-48); the only cross-GPU step
+of the whole path is merging them: sums with all_reduce(SUM), min/max with all_reduce(MIN/MAX)
+-- three tiny latency-bound collectives (RCCL over xGMI with backend "nccl", gloo on CPU for
+tests).  `best_channel` replicates ControlChannelScanner.get_best_channel's ordering
+(cc_scanner.py:355-400: synced first, then SNR descending)."""
+
+from __future__ import annotations
+
+
+def reduce_channel_stats(stats, group=None):
+    """stats: float64 tensor [M, 5] (any device).  Returns the merged tensor (same on all ranks)."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return stats
+    sums = stats[:, 0:3].contiguous()
+    mn = stats[:, 3].contiguous()
+    mx = stats[:, 4].contiguous()
+    dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(mn, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
+    return torch.cat([sums, mn[:, None], mx[:, None]], dim=1)
+
+
+def gather_measurements(meas, group=None):
+    """meas: float64 tensor [n, F] of per-stream candidate measurements
+    (power_db, snr_db, sync flag ...).  Returns [world, n, F] on every rank."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return meas[None]
+    out = [torch.empty_like(meas) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(out, meas.contiguous(), group=group)
+    return torch.stack(out)
+
+
+def activity_from_stats(stats, squelch_db: float):
+    """ScannerService._is_activity_detected (scanner.py:203-208): rssi > squelch, with
+    rssi = 10 log10(mean power + 1e-10) per channel."""
+    import torch
+
+    mean_p = stats[:, 0] / torch.clamp(stats[:, 2], min=1.0)
+    rssi = 10.0 * torch.log10(mean_p + 1e-10)
+    return rssi > squelch_db, rssi
+
+
+def best_channel(snr_db, synced):
+    """cc_scanner.py:377-400: prefer synced candidates, then highest SNR.  Returns the flat index."""
+    import torch
+
+    score = snr_db.clone().double()
+    score = torch.where(synced.bool(), score + 1e6, score)
+    return int(torch.argmax(score.reshape(-1)))
