@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Kernel-variant sweep for the fused filterbank (diagnostics; interleaved rounds in ONE process).
+usage: python tools/pfb_sweep.py "variant,gpw,ablate" ...   e.g.  1,16,0 1,32,0 1,32,1
+(variant is kept in the tuple for log compatibility; only the run length WH_PFB_GPW and the
+diagnostic WH_PFB_ABLATE (1 = no stores, 3 = nontemporal stores) are live knobs)"""
+import os, sys, statistics
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "wavecap-sdr_amd")]
+import torch
+import wavehip
+
+n = 1 << int(os.environ.get("LOG2N", "28"))
+x = torch.view_as_complex(torch.randn(n, 2, device="cuda").mul_(0.5))
+cfgs = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or [(1, 16, 0), (2, 16, 0)]
+chs = []
+for var, gpw, abl in cfgs:
+    os.environ["WH_PFB_VARIANT"], os.environ["WH_PFB_GPW"], os.environ["WH_PFB_ABLATE"] = str(var), str(gpw), str(abl)
+    ch = wavehip.PolyphaseChannelizer(10_000_000, 9765)
+    ch.profile(True)
+    chs.append(ch)
+out = torch.empty((chs[0].hops(n), 1024), dtype=torch.complex64, device="cuda")
+times = [[] for _ in chs]
+for rnd in range(6):
+    for i, ch in enumerate(chs):
+        ch.process_device(x, out)
+        t = ch.last_kernel_ms()
+        if rnd > 0:
+            times[i].append(t)
+for c, t in zip(cfgs, times):
+    med = statistics.median(t)
+    print(f"variant={c[0]} gpw={c[1]} ablate={c[2]}: median {med:.4f} ms  min {min(t):.4f}  -> {24*n/med/1e6:.0f} GB/s", flush=True)

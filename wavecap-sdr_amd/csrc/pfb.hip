@@ -19,6 +19,7 @@
 // tail hops of the fast path.
 #include "wh_common.h"
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 using namespace wh;
@@ -42,6 +43,7 @@ struct PfbFastArgs {
     long long n_groups;     // total groups of GH hops
     int groups_per_wg;
     int n_wg;
+    int ablate;             // diagnostics only (WH_PFB_ABLATE): 1 = suppress stores, 2 = skip LDS+FFT
 };
 
 __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
@@ -78,38 +80,18 @@ __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
     long long h = a.first_hop + g0 * GH;  // first hop of this run
     // windows: wA[i] = x[(h-8+i)*512 + t], wB[i] = x[(h-8+i)*512 + t + 256], i = 0..8 carried,
     // i = 9..12 filled per group
+    // window slots 0..8 carry c_{h-8..h}; slots 9..12 double as the prefetch buffer of the
+    // group's new samples (loaded one group ahead, in flight across the FFT phase)
     float2 wA[9 + GH], wB[9 + GH];
     const float2 *xp = a.x + (h - 8) * FHOP + t;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
+    for (int i = 0; i < 9 + GH; ++i) {
         wA[i] = xp[i * FHOP];
         wB[i] = xp[i * FHOP + 256];
-    }
-    // prefetch the first group's new samples
-    float2 nA[GH], nB[GH];
-#pragma unroll
-    for (int i = 0; i < GH; ++i) {
-        nA[i] = xp[(9 + i) * FHOP];
-        nB[i] = xp[(9 + i) * FHOP + 256];
     }
     __syncthreads();  // tw256 visible
 
     for (long long g = g0; g < g1; ++g, h += GH) {
-#pragma unroll
-        for (int i = 0; i < GH; ++i) {
-            wA[9 + i] = nA[i];
-            wB[9 + i] = nB[i];
-        }
-        // prefetch next group (clamped to the last group: harmless duplicate loads)
-        {
-            long long hn = (g + 1 < g1) ? h + GH : h;
-            const float2 *xn = a.x + (hn + 1) * FHOP + t;
-#pragma unroll
-            for (int i = 0; i < GH; ++i) {
-                nA[i] = xn[i * FHOP];
-                nB[i] = xn[i * FHOP + 256];
-            }
-        }
         // ---- arm MAC + radix-4 stage for GH hops --------------------------------------------
 #pragma unroll
         for (int i = 0; i < GH; ++i) {
@@ -138,11 +120,19 @@ __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
             L[2 * LDS1_K1 + t] = y2;
             L[3 * LDS1_K1 + t] = y3;
         }
-        // slide the windows
+        // slide the windows, then issue the next group's loads into the freed tail slots
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             wA[i] = wA[i + GH];
             wB[i] = wB[i + GH];
+        }
+        if (g + 1 < g1) {
+            const float2 *xn = a.x + (h + GH + 1) * FHOP + t;
+#pragma unroll
+            for (int i = 0; i < GH; ++i) {
+                wA[9 + i] = xn[i * FHOP];
+                wB[9 + i] = xn[i * FHOP + 256];
+            }
         }
         __syncthreads();
         // ---- stage 2 (radix-16 over n2) : wave = hop, lane = (k1, n3) ------------------------
@@ -179,8 +169,14 @@ __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
             }
             fft16(v);
             float2 *o = a.out + (h + wave) * FM + lane;  // k = lane + 64*k3
+            if (a.ablate == 3) {
 #pragma unroll
-            for (int k3 = 0; k3 < 16; ++k3) o[64 * k3] = v[k3];
+                for (int k3 = 0; k3 < 16; ++k3)
+                    __builtin_nontemporal_store(*reinterpret_cast<double *>(&v[k3]), reinterpret_cast<double *>(o + 64 * k3));
+            } else if (a.ablate != 1 || v[0].x == 1.2345e30f) {
+#pragma unroll
+                for (int k3 = 0; k3 < 16; ++k3) o[64 * k3] = v[k3];
+            }
         }
         __syncthreads();
     }
@@ -348,6 +344,8 @@ struct wh_pfb {
     int cur = 0;
     double *d_part = nullptr;   // stats partials
     int cu_count = 256;
+    int gpw_override = 0;       // tuning knob (WH_PFB_GPW)
+    int ablate = 0;             // diagnostics (WH_PFB_ABLATE)
     bool prof = false;          // bracket the fused kernel with events (bench roofline)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
@@ -358,6 +356,8 @@ extern "C" int wh_pfb_create(wh_pfb **out, int M, int T, const double *h_arms) {
     if ((size_t)M * 16 > 160 * 1024) return set_err(WH_E_ARG, "wh_pfb_create: M=%d exceeds the LDS-resident limit", M);
     wh_pfb *p = new wh_pfb();
     p->M = M; p->T = T;
+    if (const char *e = getenv("WH_PFB_GPW")) p->gpw_override = atoi(e);
+    if (const char *e = getenv("WH_PFB_ABLATE")) p->ablate = atoi(e);
     int l2 = 0;
     while ((1 << l2) < M) ++l2;
     p->log2M = ((1 << l2) == M) ? l2 : 0;
@@ -470,15 +470,20 @@ extern "C" int wh_pfb_run(wh_pfb *p, const float *d_iq, size_t n, float *d_out, 
             a.tw1024 = p->d_tw;
             a.first_hop = 8;
             a.n_groups = n_groups;
-            // runs of ~64 hops, but at least ~8 workgroups per CU when the input allows
-            int gpw = 16;
+            // runs of 128 hops (halo 7 %), but at least ~8 workgroups per CU when the input allows
+            int gpw = 32;
             long long nwg = (n_groups + gpw - 1) / gpw;
             while (gpw > 2 && nwg < (long long)p->cu_count * 8) {
                 gpw >>= 1;
                 nwg = (n_groups + gpw - 1) / gpw;
             }
+            if (p->gpw_override > 0) {
+                gpw = p->gpw_override;
+                nwg = (n_groups + gpw - 1) / gpw;
+            }
             a.groups_per_wg = gpw;
             a.n_wg = (int)nwg;
+            a.ablate = p->ablate;
             if (p->prof) WH_HIP(hipEventRecord(p->ev0, st));
             hipLaunchKernelGGL(pfb1024_kernel, dim3((unsigned)nwg), dim3(256), 0, st, a);
             WH_LAUNCH_CHECK();

@@ -139,13 +139,14 @@ class ChannelBank:
                     cfg.h_mpx_b, cfg.h_mpx_a = _lib.dptr(b, "f64"), _lib.dptr(a, "f64")
                     keep += [b, a]
         self._h = C.c_void_p()
+        self._destroy = _lib.lib.wh_fmbank_destroy
         _lib.check(_lib.lib.wh_fmbank_create(C.byref(self._h), C.byref(cfg)), "wh_fmbank_create")
         del keep
 
     def __del__(self):
-        h = getattr(self, "_h", None)
-        if h:
-            _lib.lib.wh_fmbank_destroy(h)
+        h, destroy = getattr(self, "_h", None), getattr(self, "_destroy", None)
+        if h and destroy:
+            destroy(h)
             self._h = None
 
     def process_device(self, d_in, n_chunks: int, audio=None, metrics=None):

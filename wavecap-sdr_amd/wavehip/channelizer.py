@@ -35,6 +35,7 @@ class PolyphaseChannelizer:
         self.block_counter = 0
         self._torch = _lib.require_gpu()
         self._h = C.c_void_p()
+        self._destroy = _lib.lib.wh_pfb_destroy
         arms = np.ascontiguousarray(self.arms, dtype=np.float64)
         _lib.check(_lib.lib.wh_pfb_create(C.byref(self._h), self.channel_count, self.taps_per_channel,
                                           _lib.dptr(arms, "f64")), "wh_pfb_create")
@@ -50,9 +51,9 @@ class PolyphaseChannelizer:
             self.arms[arm, : len(t)] = t
 
     def __del__(self):
-        h = getattr(self, "_h", None)
-        if h:
-            _lib.lib.wh_pfb_destroy(h)
+        h, destroy = getattr(self, "_h", None), getattr(self, "_destroy", None)
+        if h and destroy:
+            destroy(h)
             self._h = None
 
     # -- carried state ---------------------------------------------------------------------

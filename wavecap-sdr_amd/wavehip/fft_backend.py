@@ -78,13 +78,14 @@ class HipFFTBackend(FFTBackend):
         super().__init__(fft_size)
         self._lib, self._torch = _lib, torch
         self._h = C.c_void_p()
+        self._destroy = _lib.lib.wh_spectrum_destroy
         _lib.check(_lib.lib.wh_spectrum_create(C.byref(self._h), int(fft_size)), "wh_spectrum_create")
         self._freq_cache: dict[int, np.ndarray] = {}
 
     def __del__(self):
-        h = getattr(self, "_h", None)
-        if h:
-            self._lib.lib.wh_spectrum_destroy(h)
+        h, destroy = getattr(self, "_h", None), getattr(self, "_destroy", None)
+        if h and destroy:
+            destroy(h)
             self._h = None
 
     def _freqs(self, sample_rate: int) -> np.ndarray:
