@@ -251,8 +251,13 @@ def gen_c4fm():
         d = rc4.C4FMDemodulator(sample_rate=fs)
         out[f"lpf_{fs}"] = d._baseband_lpf
         out[f"rrc_{fs}"] = d._rrc_filter
-    out["interp_taps"] = rc4._interpolator.TAPS.copy()
     save("c4fm", **out)
+    # The 129x8 MMSE interpolator coefficient table (GNU Radio / SDRTrunk constants) is data the
+    # algorithm is defined by; stored as binary fixtures for the oracle and for the product.
+    taps = np.ascontiguousarray(rc4._interpolator.TAPS, dtype=np.float32)
+    np.save(os.path.join(GOLD, "mmse_interp_taps_f32.npy"), taps)
+    os.makedirs(os.path.join(REPO, "wavecap-sdr_amd", "wavehip", "data"), exist_ok=True)
+    np.save(os.path.join(REPO, "wavecap-sdr_amd", "wavehip", "data", "mmse_interp_taps_f32.npy"), taps)
 
 
 ALL = dict(a1=gen_a1, a2=gen_a2, a3=gen_a3, a6=gen_a6, chain=gen_chain, a7=gen_a7, a8=gen_a8, c4fm=gen_c4fm)
