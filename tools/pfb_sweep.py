@@ -19,6 +19,16 @@ for var, gpw, abl in cfgs:
     ch.profile(True)
     chs.append(ch)
 out = torch.empty((chs[0].hops(n), 1024), dtype=torch.complex64, device="cuda")
+# in-run yardstick: plain device copy of 4 GiB (read 4 + write 4), same process, same box
+src = torch.empty(1 << 30, dtype=torch.float32, device="cuda").normal_()
+dst = torch.empty_like(src)
+ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+cp = []
+for _ in range(6):
+    ev0.record(); dst.copy_(src); ev1.record(); torch.cuda.synchronize()
+    cp.append(ev0.elapsed_time(ev1))
+print(f"copy yardstick: 8 GiB moved in {statistics.median(cp[1:]):.4f} ms -> {8*(1<<30)/statistics.median(cp[1:])/1e6:.0f} GB/s", flush=True)
+del src, dst
 times = [[] for _ in chs]
 for rnd in range(6):
     for i, ch in enumerate(chs):

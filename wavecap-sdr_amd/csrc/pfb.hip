@@ -75,7 +75,10 @@ __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
 
     // stage-1 twiddles W1024^(t*k1), k1 = 1..3
     float2 tw1 = a.tw1024[t], tw2 = a.tw1024[(2 * t) & 1023], tw3 = a.tw1024[(3 * t) & 1023];
+    // stage-2 twiddles W256^(n3*k2) are read from a 2 KB LDS table (keeping the 15 per-lane values
+    // in registers instead pushes the kernel to 256 VGPRs and measured 18 % slower)
     tw256[t] = a.tw1024[4 * t];
+    __syncthreads();
 
     long long h = a.first_hop + g0 * GH;  // first hop of this run
     // windows: wA[i] = x[(h-8+i)*512 + t], wB[i] = x[(h-8+i)*512 + t + 256], i = 0..8 carried,
@@ -89,7 +92,6 @@ __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
         wA[i] = xp[i * FHOP];
         wB[i] = xp[i * FHOP + 256];
     }
-    __syncthreads();  // tw256 visible
 
     for (long long g = g0; g < g1; ++g, h += GH) {
         // ---- arm MAC + radix-4 stage for GH hops --------------------------------------------
