@@ -62,38 +62,53 @@ int wh_resampler_run(wh_resampler *r, const float *d_x, size_t n_in, size_t batc
 void wh_resampler_destroy(wh_resampler *r);
 
 /* ---- Channel operator, batched: capture.py:298-439 _process_channel_dsp_stateless
- * for modes "nbfm"/"wbfm" over K channels of one capture (replaces the per-channel
- * ThreadPoolExecutor fan-out of capture.py:2489-2597).
+ * for the analog modes nbfm / wbfm / am / ssb over K channels of one capture (replaces the
+ * per-channel ThreadPoolExecutor fan-out of capture.py:2489-2597).
  *   input : one chunk-major IQ buffer shared by all channels, int16 interleaved
  *           (format 1, A1 unpack rule fused) or complex64 (format 0);
  *   output: d_audio float32[n_chunks][K][n_out], d_metrics float32[n_chunks][K][4] =
  *           {rssi_db, signal_power_db, max_abs_audio, finite_flag} (capture.py:331-334,
  *           432-437; validation.py:41-52 is applied by the host shim from the last two).
- * mode: 0 = nbfm (all optional filters off = NBFM mode default, capture.py:3444-3452)
- *       1 = wbfm (de-emphasis + MPX low-pass, WBFM mode default); IIR coefficients
- *           are given by the host: deemph_b0/a1 (float32 one-pole, dsp/fm.py:101-108),
- *           mpx_b/mpx_a float64[6] (butter(5), dsp/fm.py:129-144), NULL = stage off.   */
-typedef struct wh_fmbank wh_fmbank;
-typedef struct wh_fmbank_cfg {
+ * Chain: NCO mix (capture.py:166-193) -> demod front -> IIR stages -> [AGC] -> resample_poly ->
+ * post.  The host designs every filter exactly as the reference does and passes coefficients:
+ *   demod 0 FM discriminator (dsp/fm.py:65-97), 1 AM envelope (dsp/am.py:103),
+ *         2 SSB product detector with float64-phase BFO at bfo_hz (dsp/am.py:23-42, 200-210);
+ *   stages: lfilter(b, a) sections in application order, float32 (de-emphasis, dsp/fm.py:101-126)
+ *         or float64 (Butterworth / notch, dsp/filters.py:86-264, dsp/fm.py:129-181), zero state
+ *         per chunk, output of each rounded to float32;
+ *   agc : dsp/agc.py:169-242 (float32 attack/release one-poles, gain cap, tanh soft clip);
+ *   post 0: rms_normalize(0.18) + FM soft clip x0.95 (dsp/fm.py:26-62) -- FM modes
+ *        1: AM/SSB: nothing after AGC, agc.soft_clip when agc == 0 (dsp/am.py:135-139);
+ *   ntaps == 0: sample_rate == audio_rate, no resampling (dsp/fm.py:198-199), n_out == chunk_len. */
+typedef struct wh_iir_stage {
+    int is_f64;             /* 1: float64 recurrence, 0: float32 */
+    int n;                  /* max(len(b), len(a)) <= 11, shorter one zero padded */
+    double b[11], a[11];
+} wh_iir_stage;
+typedef struct wh_chanbank wh_chanbank;
+typedef struct wh_chanbank_cfg {
     int sample_rate;
     int chunk_len;          /* N samples per chunk (capture.py:3035) */
     int n_channels;
     const int *h_offsets_hz;/* round(offset_hz) per channel; 0 = no mix (capture.py:328) */
     int input_format;       /* 0 = complex64, 1 = int16 IQ */
-    int mode;               /* 0 nbfm, 1 wbfm */
-    const double *h_taps;   /* resample_poly taps (see wh_resampler_create) */
+    int demod;              /* 0 FM, 1 AM, 2 SSB */
+    double bfo_hz;          /* demod 2: +bfo (USB) / -bfo (LSB) */
+    int n_stages;           /* <= 8 */
+    const wh_iir_stage *h_stages;
+    int agc;
+    float agc_target, agc_max_gain;                 /* float32(10^(target_db/20)), float32(10^(60/20)) */
+    float agc_att_b0, agc_att_a1, agc_rel_b0, agc_rel_a1; /* float32 one-pole coefficient arrays */
+    int post;               /* 0 FM, 1 AM/SSB */
+    const double *h_taps;   /* resample_poly taps (see wh_resampler_create); NULL when ntaps == 0 */
     int ntaps, up, down, d0;
-    int n_out;              /* ceil(N*up/down) */
-    float deemph_b0;        /* wbfm only: float32 b[0] of dsp/fm.py:106; <=0 disables */
-    float deemph_a1;        /* wbfm only: float32 a[1] = -(1-alpha) of dsp/fm.py:107 */
-    const double *h_mpx_b;  /* wbfm only; NULL disables */
-    const double *h_mpx_a;
-} wh_fmbank_cfg;
-int wh_fmbank_create(wh_fmbank **out, const wh_fmbank_cfg *cfg);
-int wh_fmbank_run(wh_fmbank *b, const void *d_in, size_t n_chunks, float *d_audio, float *d_metrics,
-                  void *stream);
-size_t wh_fmbank_workspace_bytes(const wh_fmbank *b, size_t n_chunks);
-void wh_fmbank_destroy(wh_fmbank *b);
+    int n_out;              /* ceil(N*up/down), or N when ntaps == 0 */
+} wh_chanbank_cfg;
+int wh_chanbank_create(wh_chanbank **out, const wh_chanbank_cfg *cfg);
+int wh_chanbank_run(wh_chanbank *b, const void *d_in, size_t n_chunks, float *d_audio, float *d_metrics,
+                    void *stream);
+size_t wh_chanbank_workspace_bytes(const wh_chanbank *b, size_t n_chunks);
+void wh_chanbank_destroy(wh_chanbank *b);
 
 /* ---- A7: polyphase channelizer, dsp/channelizer.py:28-158 PolyphaseChannelizer ----
  * h_arms: float64[M][T] exactly as _design_filter builds them (channelizer.py:69-89).

@@ -309,6 +309,129 @@ def process_channel_wbfm(samples: np.ndarray, sample_rate: int, offset_hz: float
 
 
 # --------------------------------------------------------------------------
+# A14  AM / SSB / AGC / optional FM filters (dispatcher modes am, ssb; capture.py:371-414)
+# --------------------------------------------------------------------------
+
+
+def notch_filter(x: np.ndarray, sample_rate: int, freq: float, q: float = 30.0) -> np.ndarray:
+    """dsp/filters.py:224-264 -- iirnotch applied with lfilter (float64), float32 out."""
+    nf = freq / (sample_rate / 2.0)
+    if x.size == 0 or nf <= 0 or nf >= 1.0:
+        return x.astype(np.float32, copy=False)
+    b, a = _sig.iirnotch(nf, q)
+    return _sig.lfilter(b, a, x).astype(np.float32)
+
+
+def agc_coeffs(sample_rate: int, attack_ms: float = 5.0, release_ms: float = 50.0):
+    """dsp/agc.py:215-219."""
+    attack_samples = (attack_ms / 1000.0) * sample_rate
+    release_samples = (release_ms / 1000.0) * sample_rate
+    ac = 1.0 - np.exp(-1.0 / attack_samples) if attack_samples > 0 else 1.0
+    rc = 1.0 - np.exp(-1.0 / release_samples) if release_samples > 0 else 1.0
+    return ac, rc
+
+
+def apply_agc(x: np.ndarray, sample_rate: int, target_db: float = -20.0, attack_ms: float = 5.0,
+              release_ms: float = 50.0, max_gain_db: float = 60.0) -> np.ndarray:
+    """dsp/agc.py:169-242 with the scipy envelope detector (:73-108): two cascaded float32
+    one-poles on |x|, envelope = max of both, gain = target/max(env, 1e-6) capped, soft clip."""
+    if x.size == 0:
+        return x.astype(np.float32, copy=False)
+    target_linear = 10.0 ** (target_db / 20.0)
+    max_gain_linear = 10.0 ** (max_gain_db / 20.0)
+    ac, rc = agc_coeffs(sample_rate, attack_ms, release_ms)
+    abs_x = np.abs(x).astype(np.float32)
+    env_a = _sig.lfilter(np.array([ac], dtype=np.float32), np.array([1.0, -(1.0 - ac)], dtype=np.float32), abs_x)
+    env_r = _sig.lfilter(np.array([rc], dtype=np.float32), np.array([1.0, -(1.0 - rc)], dtype=np.float32), env_a)
+    envelope = np.maximum(env_a, env_r).astype(np.float32)
+    gain = target_linear / np.maximum(envelope, 1e-6)
+    np.minimum(gain, max_gain_linear, out=gain)
+    y = x * gain
+    return soft_clip_agc(y).astype(np.float32)
+
+
+def am_demod(iq: np.ndarray, sample_rate: int, audio_rate: int = 48_000, enable_agc: bool = True,
+             enable_highpass: bool = True, highpass_hz: float = 100, enable_lowpass: bool = True,
+             lowpass_hz: float = 5000, agc_target_db: float = -20.0, notch_frequencies=None) -> np.ndarray:
+    """dsp/am.py:45-141."""
+    if iq.size == 0:
+        return np.empty(0, dtype=np.float32)
+    audio = np.abs(iq).astype(np.float32)
+    if enable_highpass and highpass_hz > 0:
+        audio = butter_filter(audio, sample_rate, "high", highpass_hz)
+    if enable_lowpass and lowpass_hz > 0:
+        audio = butter_filter(audio, sample_rate, "low", lowpass_hz)
+    for f in notch_frequencies or []:
+        if 0 < f < sample_rate / 2:
+            audio = notch_filter(audio, sample_rate, f)
+    if enable_agc:
+        audio = apply_agc(audio, sample_rate, target_db=agc_target_db)
+    audio = resample_poly(audio, sample_rate, audio_rate)
+    if not enable_agc:
+        audio = soft_clip_agc(audio)
+    return audio
+
+
+def ssb_demod(iq: np.ndarray, sample_rate: int, audio_rate: int = 48_000, mode: str = "usb",
+              enable_agc: bool = True, enable_bandpass: bool = True, bandpass_low: float = 300,
+              bandpass_high: float = 3000, agc_target_db: float = -20.0, notch_frequencies=None,
+              bfo_offset_hz: float = 1500.0) -> np.ndarray:
+    """dsp/am.py:144-247 (BFO: float64 phase, + sign, dsp/am.py:23-42)."""
+    if iq.size == 0:
+        return np.empty(0, dtype=np.float32)
+    shift_hz = bfo_offset_hz if mode.lower() == "usb" else -bfo_offset_hz
+    t = np.arange(iq.shape[0], dtype=np.float64) / float(sample_rate)
+    shift = np.exp(2j * np.pi * shift_hz * t).astype(np.complex64)
+    audio = np.real((iq * shift).astype(np.complex64)).astype(np.float32)
+    if enable_bandpass:
+        audio = butter_filter(audio, sample_rate, "band", (bandpass_low, bandpass_high))
+    for f in notch_frequencies or []:
+        if 0 < f < sample_rate / 2:
+            audio = notch_filter(audio, sample_rate, f)
+    if enable_agc:
+        audio = apply_agc(audio, sample_rate, target_db=agc_target_db)
+    audio = resample_poly(audio, sample_rate, audio_rate)
+    if not enable_agc:
+        audio = soft_clip_agc(audio)
+    return audio
+
+
+def fm_demod_filtered(iq: np.ndarray, sample_rate: int, audio_rate: int = 48_000, *, deemphasis_tau=None,
+                      mpx_cutoff_hz=None, highpass_hz=None, lowpass_hz=None, notch_frequencies=None) -> np.ndarray:
+    """dsp/fm.py:228-406 with any subset of the optional IIR stages, in the reference's order:
+    de-emphasis, [wbfm: MPX low-pass], high-pass, [nbfm: low-pass], notches."""
+    fm = quadrature_demod(iq, sample_rate)
+    if deemphasis_tau is not None:
+        fm = deemphasis_filter(fm, sample_rate, tau=deemphasis_tau)
+    if mpx_cutoff_hz is not None:
+        fm = lpf_audio(fm, sample_rate, cutoff=mpx_cutoff_hz)
+    if highpass_hz is not None and highpass_hz > 0:
+        fm = butter_filter(fm, sample_rate, "high", highpass_hz)
+    if lowpass_hz is not None and lowpass_hz > 0:
+        fm = butter_filter(fm, sample_rate, "low", lowpass_hz)
+    for f in notch_frequencies or []:
+        if 0 < f < sample_rate / 2:
+            fm = notch_filter(fm, sample_rate, f)
+    fm = rms_normalize(fm, target_rms=0.18)
+    audio = resample_poly(fm, sample_rate, audio_rate)
+    return soft_clip_fm(audio)
+
+
+def process_channel(samples: np.ndarray, sample_rate: int, offset_hz: float, demod, **kw):
+    """capture.py:298-439 around an arbitrary demodulator `demod(base, sample_rate, **kw)`."""
+    metrics = {}
+    if samples.size == 0 or not np.isfinite(samples).all():
+        return None, metrics
+    base = samples if offset_hz == 0.0 else freq_shift(samples, offset_hz, sample_rate)
+    metrics["rssi_db"] = channel_metrics_db(base)
+    audio = demod(base, sample_rate, **kw)
+    if not np.isfinite(audio).all() or float(np.max(np.abs(audio))) > 1.2:
+        return None, metrics
+    metrics["signal_power_db"] = channel_metrics_db(audio)
+    return audio, metrics
+
+
+# --------------------------------------------------------------------------
 # A7  2x-oversampled polyphase filterbank
 # --------------------------------------------------------------------------
 

@@ -180,6 +180,40 @@ def test_chain_wbfm(wh, golden):
         assert np.allclose([met["rssi_db"], met["signal_power_db"]], g[f"wbfm{ci}_met"], atol=2e-4)
 
 
+def test_chain_am_ssb_filtered_fm(wh, golden, O):
+    """Dispatcher modes am / ssb (AGC, Butterworth, BFO) and NBFM with every optional IIR stage,
+    against the reference goldens, plus the oracle on a second seed."""
+    from test_oracle_golden import analog_cases
+
+    g = golden("chain_analog")
+    C = wh.ChannelConfig
+    cfgs = {
+        "am48": C(mode="am", offset_hz=4800.0, enable_agc=True),
+        "am48to24": C(mode="am", offset_hz=4800.0, enable_agc=True, audio_rate=24000),
+        "am48noagc": C(mode="am", offset_hz=4800.0, enable_agc=False),
+        "am96nohp": C(mode="am", offset_hz=9600.0, enable_agc=True, enable_am_highpass=False),
+        "ssb32usb": C(mode="ssb", offset_hz=3200.0, enable_agc=True, ssb_mode="usb"),
+        "ssb32lsb": C(mode="ssb", offset_hz=3200.0, enable_agc=True, ssb_mode="lsb"),
+        "nbfmf96": C(mode="nbfm", offset_hz=12000.0, enable_deemphasis=True, enable_fm_highpass=True,
+                     fm_highpass_hz=300, enable_fm_lowpass=True, fm_lowpass_hz=3000, notch_frequencies=[1000.0]),
+    }
+    for tag, mk, fs, off, demod, kw in analog_cases():
+        iq = mk()
+        audio, met = wh.process_channel_dsp_stateless(iq, fs, cfgs[tag])
+        assert audio is not None and audio.shape == g[f"{tag}_audio"].shape, tag
+        assert peak_rel_err(audio, g[f"{tag}_audio"]) <= TOL, tag
+        assert np.allclose([met["rssi_db"], met["signal_power_db"]], g[f"{tag}_met"], atol=2e-4), tag
+    # a bank of 3 AM channels on one chunk vs the oracle
+    fs, n = 48000, 4800
+    iq = (S.am_tone_c64(n, fs, 61, carrier_hz=3000.0) + S.am_tone_c64(n, fs, 62, carrier_hz=-7000.0, audio_hz=500.0)
+          + S.am_tone_c64(n, fs, 63, carrier_hz=12000.0, audio_hz=1200.0)).astype(np.complex64)
+    offs = [3000.0, -7000.0, 12000.0]
+    res = wh.ChannelBank(fs, n, [C(mode="am", offset_hz=o, enable_agc=True) for o in offs]).process(iq)
+    for k, o in enumerate(offs):
+        a_ref, _ = O.process_channel(iq, fs, o, O.am_demod)
+        assert peak_rel_err(res[k][0], a_ref) <= TOL, k
+
+
 def test_a7_pfb_golden(wh, golden):
     g = golden("a7_pfb")
     for ci in range(int(g["n_cases"])):

@@ -117,16 +117,27 @@ __global__ __launch_bounds__(256) void resample_kernel(const float *x, size_t n_
     if (lane == 0) y[b * n_out + m] = (float)acc;
 }
 
-// ---- fmbank ---------------------------------------------------------------------------------
+// ---- channel bank -----------------------------------------------------------------------------
+constexpr int MAX_STAGES = 8;
+constexpr int MAX_ORD = 11;   // coefficients per stage (butter(5) band-pass = order 10)
+
+struct StageDev {
+    int is_f64, n;
+    double b[MAX_ORD], a[MAX_ORD];
+};
+
 struct FmArgs {
     const void *in;     // [n_chunks][N] int16x2 or float2
     float *audio;       // [n_chunks][K][n_out]   (unscaled FIR output until finalize)
-    double *acc;        // [n_chunks][K][2] = {sum |base|^2, sum fm^2}
-    float *fm_out;      // unfused path: [n_chunks][K][N] discriminator output
+    double *acc;        // [n_chunks][K][2] = {sum |base|^2, sum v^2}
+    float *fm_out;      // unfused path: [n_chunks][K][N] demodulated rows
     const float *nco_c; // [K] f32(-2 pi off/fs); 0 => no mix
     const double *taps; // [ntaps]
     int fmt, N, K, n_out, ntaps, down, d0, TO;
     float scale;        // fs / (2 pi 75000)
+    int demod;          // 0 FM discriminator, 1 AM envelope, 2 SSB product detector
+    double bfo_c;       // 2 pi bfo_hz (SSB), sample_rate in fs_d
+    double fs_d;
 };
 
 constexpr int FM_MAX_SPAN = 8192;    // floats of fm kept in LDS (32 KiB -> 4 workgroups per CU)
@@ -208,8 +219,9 @@ __global__ __launch_bounds__(256) void fmbank_fused_kernel(FmArgs a) {
     if (o < mcnt && sub == 0) a.audio[((size_t)chunk * a.K + k) * a.n_out + m0 + o] = (float)accv;
 }
 
-// unfused first stage (wbfm, or up != 1): discriminator to HBM + power sums
-__global__ __launch_bounds__(256) void fmbank_disc_kernel(FmArgs a) {
+// unfused first stage: NCO mix + demodulator front (FM discriminator / AM envelope / SSB product
+// detector) to HBM rows + power sums
+__global__ __launch_bounds__(256) void chan_front_kernel(FmArgs a) {
     const int k = blockIdx.y, chunk = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = a.N;
@@ -233,10 +245,20 @@ __global__ __launch_bounds__(256) void fmbank_disc_kernel(FmArgs a) {
         prv.y = __shfl_up(bse.y, 1);
         if (lane > 0 && valid && n < b_hi) {
             float v = 0.f;
-            if (n >= 1) {
-                float re = bse.x * prv.x + bse.y * prv.y;
-                float im = bse.y * prv.x - bse.x * prv.y;
-                v = whm_atan2f(im, re) * a.scale;
+            if (a.demod == 0) {          // dsp/fm.py:65-97
+                if (n >= 1) {
+                    float re = bse.x * prv.x + bse.y * prv.y;
+                    float im = bse.y * prv.x - bse.x * prv.y;
+                    v = whm_atan2f(im, re) * a.scale;
+                }
+            } else if (a.demod == 1) {   // dsp/am.py:103 np.abs(iq)
+                v = hypotf(bse.x, bse.y);
+            } else {                     // dsp/am.py:23-42, 204-210: BFO with float64 phase, + sign; real part
+                double t = (double)n / a.fs_d;
+                double th = a.bfo_c * t;
+                double sn, cs;
+                sincos(th, &sn, &cs);
+                v = __fsub_rn(__fmul_rn(bse.x, (float)cs), __fmul_rn(bse.y, (float)sn));
             }
             fm[n] = v;
             p_base += bse.x * bse.x + bse.y * bse.y;
@@ -260,63 +282,93 @@ __global__ __launch_bounds__(256) void fmbank_disc_kernel(FmArgs a) {
     }
 }
 
-// wbfm IIR stages on one (chunk, channel) row, zero initial state (dsp/fm.py:111-181):
-// de-emphasis one-pole in float32 (lfilter DF2T on float32 data), then butter(5) in float64,
-// output rounded to float32 after each stage like the reference's .astype(np.float32).
-// One lane per row; rows are independent (stateless per chunk).  Also re-accumulates sum fm^2.
-__global__ void wbfm_iir_kernel(float *fm, double *acc, int rows, int N, float alpha, float neg_a1,
-                                const double *ba /* b[6], a[6] or null */, int use_mpx) {
-    int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rows) return;
-    float *f = fm + (size_t)r * N;
-    float z1 = 0.f;
-    double b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0;
-    if (use_mpx) {
-        b0 = ba[0]; b1 = ba[1]; b2 = ba[2]; b3 = ba[3]; b4 = ba[4]; b5 = ba[5];
-        a1 = ba[7]; a2 = ba[8]; a3 = ba[9]; a4 = ba[10]; a5 = ba[11];
-    }
-    double z[5] = {0, 0, 0, 0, 0};
+// Sequential IIR stages on one (chunk, channel) row, zero initial state per chunk (stateless
+// operator): scipy.signal.lfilter's direct-form-II-transposed recurrence in the stage's dtype
+// (float32 stages: de-emphasis dsp/fm.py:101-126, AGC one-poles; float64 stages: Butterworth /
+// notch, dsp/filters.py:86-264, dsp/fm.py:129-181), each output rounded to float32 like the
+// reference's .astype(np.float32); optional AGC (dsp/agc.py:169-242).  One lane per row.
+struct AgcDev {
+    int on;
+    float target, max_gain, att_b0, att_a1, rel_b0, rel_a1;
+};
+
+__global__ __launch_bounds__(64) void chan_rows_kernel(float *rows, double *acc, int n_rows, int N,
+                                                      const StageDev *stages, int n_stages, AgcDev agc) {
+    __shared__ StageDev st_s[MAX_STAGES];
+    __shared__ double z_s[MAX_STAGES][MAX_ORD - 1][64];   // filter state, [stage][k][lane]
+    const int lane = threadIdx.x;
+    for (int i = lane; i < n_stages * (int)(sizeof(StageDev) / 4); i += 64)
+        reinterpret_cast<int *>(st_s)[i] = reinterpret_cast<const int *>(stages)[i];
+    for (int s = 0; s < n_stages; ++s)
+        for (int k = 0; k < MAX_ORD - 1; ++k) z_s[s][k][lane] = 0.0;
+    __syncthreads();
+    const int r = blockIdx.x * 64 + lane;
+    if (r >= n_rows) return;
+    float *f = rows + (size_t)r * N;
+    float za = 0.f, zr = 0.f;
+    const float NORM = (float)(1.0 / 0.90514825364486640);
     double ss = 0.0;
-    for (int n = 0; n < N; ++n) {
-        float x = f[n];
-        if (alpha > 0.f) {
-            // DF2T with b = [b0], a = [1, a1]:  y = b0*x + z ; z = -a1*y
-            float y = __fadd_rn(__fmul_rn(alpha, x), z1);
-            z1 = __fmul_rn(neg_a1, y);
-            x = y;
+    for (int i = 0; i < N; ++i) {
+        float x = f[i];
+        for (int s = 0; s < n_stages; ++s) {
+            const StageDev &S = st_s[s];
+            const int n = S.n;
+            if (S.is_f64) {
+                double xd = (double)x;
+                double y = __dadd_rn(z_s[s][0][lane], __dmul_rn(S.b[0], xd));
+                for (int k = 0; k < n - 2; ++k)
+                    z_s[s][k][lane] = __dsub_rn(__dadd_rn(z_s[s][k + 1][lane], __dmul_rn(xd, S.b[k + 1])),
+                                                __dmul_rn(y, S.a[k + 1]));
+                if (n >= 2) z_s[s][n - 2][lane] = __dsub_rn(__dmul_rn(xd, S.b[n - 1]), __dmul_rn(y, S.a[n - 1]));
+                x = (float)y;
+            } else {
+                float y = __fadd_rn((float)z_s[s][0][lane], __fmul_rn((float)S.b[0], x));
+                for (int k = 0; k < n - 2; ++k)
+                    z_s[s][k][lane] = (double)__fsub_rn(__fadd_rn((float)z_s[s][k + 1][lane], __fmul_rn(x, (float)S.b[k + 1])),
+                                                        __fmul_rn(y, (float)S.a[k + 1]));
+                if (n >= 2)
+                    z_s[s][n - 2][lane] = (double)__fsub_rn(__fmul_rn(x, (float)S.b[n - 1]), __fmul_rn(y, (float)S.a[n - 1]));
+                x = y;
+            }
         }
-        if (use_mpx) {
-            double xd = (double)x;
-            double y = __dadd_rn(__dmul_rn(b0, xd), z[0]);
-            z[0] = __dsub_rn(__dadd_rn(__dmul_rn(b1, xd), z[1]), __dmul_rn(a1, y));
-            z[1] = __dsub_rn(__dadd_rn(__dmul_rn(b2, xd), z[2]), __dmul_rn(a2, y));
-            z[2] = __dsub_rn(__dadd_rn(__dmul_rn(b3, xd), z[3]), __dmul_rn(a3, y));
-            z[3] = __dsub_rn(__dadd_rn(__dmul_rn(b4, xd), z[4]), __dmul_rn(a4, y));
-            z[4] = __dsub_rn(__dmul_rn(b5, xd), __dmul_rn(a5, y));
-            x = (float)y;
+        if (agc.on) {
+            float ax = fabsf(x);
+            float ya = __fadd_rn(za, __fmul_rn(agc.att_b0, ax));
+            za = __fsub_rn(__fmul_rn(ax, 0.0f), __fmul_rn(ya, agc.att_a1));
+            float yr = __fadd_rn(zr, __fmul_rn(agc.rel_b0, ya));
+            zr = __fsub_rn(__fmul_rn(ya, 0.0f), __fmul_rn(yr, agc.rel_a1));
+            float env = fmaxf(ya, yr);
+            float g = __fdiv_rn(agc.target, fmaxf(env, (float)1e-6));
+            g = fminf(g, agc.max_gain);
+            float y = __fmul_rn(x, g);
+            x = tanhf(y * 1.5f) * NORM;
         }
-        f[n] = x;
+        f[i] = x;
         ss += (double)x * (double)x;
     }
     acc[(size_t)r * 2 + 1] = ss;
 }
 
-// finalize: scale by 0.18/rms (dsp/fm.py:42-62), soft clip (fm.py:26-39), metrics
+// finalize.  post 0 (FM): scale by 0.18/rms (dsp/fm.py:42-62) + soft clip x0.95 (fm.py:26-39);
+// post 1 (AM/SSB with AGC): audio as is;  post 2 (AM/SSB without AGC): agc.soft_clip (agc.py:58-70)
 __global__ __launch_bounds__(256) void fmbank_finalize_kernel(float *audio, const double *acc, float *metrics,
-                                                              int N, int n_out) {
+                                                              int N, int n_out, int post) {
     const size_t row = blockIdx.x;
     float *au = audio + row * n_out;
     const double *ac = acc + row * 2;
-    const float mean_fm = (float)(ac[1] / (double)N);
-    const float rms = sqrtf(mean_fm);
     float s = 1.0f;
-    if ((double)rms > 1e-4) s = (float)(0.18 / (double)rms);
+    if (post == 0) {
+        const float mean_fm = (float)(ac[1] / (double)N);
+        const float rms = sqrtf(mean_fm);
+        if ((double)rms > 1e-4) s = (float)(0.18 / (double)rms);
+    }
     const float NORM = (float)(1.0 / 0.90514825364486640);  // 1/tanh(1.5)
     float p = 0.f, mx = 0.f;
     int bad = 0;
     for (int i = threadIdx.x; i < n_out; i += 256) {
-        float v = au[i] * s;
-        v = tanhf(v * 1.5f) * NORM * 0.95f;
+        float v = au[i];
+        if (post == 0) v = tanhf((v * s) * 1.5f) * NORM * 0.95f;
+        else if (post == 2) v = tanhf(v * 1.5f) * NORM;
         au[i] = v;
         p += v * v;
         mx = fmaxf(mx, fabsf(v));
@@ -451,47 +503,70 @@ extern "C" int wh_resampler_run(wh_resampler *r, const float *d_x, size_t n_in, 
     return launch_resample(d_x, n_in, batch, d_y, n_out, r->d_taps, r->ntaps, r->up, r->down, r->d0, as_stream(stream));
 }
 
-struct wh_fmbank {
-    wh_fmbank_cfg cfg;
+struct wh_chanbank {
+    wh_chanbank_cfg cfg;
     float *d_nco = nullptr;
     double *d_taps = nullptr;
-    double *d_ba = nullptr;
+    StageDev *d_stages = nullptr;
     double *d_acc = nullptr;
     float *d_fm = nullptr;
     size_t cap_chunks = 0;
     bool fused = false;
     int TO = 128;
     size_t smem = 0;
+    int post = 0;
 };
 
-extern "C" int wh_fmbank_create(wh_fmbank **out, const wh_fmbank_cfg *c) {
-    if (!out || !c || !c->h_offsets_hz || !c->h_taps) return set_err(WH_E_ARG, "wh_fmbank_create: null");
-    if (c->n_channels < 1 || c->n_channels > 65535 || c->chunk_len < 2 || c->chunk_len > (1 << 24) || c->ntaps < 1 ||
-        c->up < 1 || c->down < 1 || c->n_out < 1 || (c->mode != 0 && c->mode != 1) ||
-        (c->input_format != 0 && c->input_format != 1))
-        return set_err(WH_E_ARG, "wh_fmbank_create: bad configuration");
-    wh_fmbank *b = new wh_fmbank();
+extern "C" int wh_chanbank_create(wh_chanbank **out, const wh_chanbank_cfg *c) {
+    if (!out || !c || !c->h_offsets_hz) return set_err(WH_E_ARG, "wh_chanbank_create: null");
+    const bool resample = c->ntaps > 0;
+    if (c->n_channels < 1 || c->n_channels > 65535 || c->chunk_len < 2 || c->chunk_len > (1 << 24) ||
+        (resample && (!c->h_taps || c->up < 1 || c->down < 1)) || c->n_out < 1 || c->demod < 0 || c->demod > 2 ||
+        (c->input_format != 0 && c->input_format != 1) || c->n_stages < 0 || c->n_stages > MAX_STAGES ||
+        (c->n_stages > 0 && !c->h_stages) || c->post < 0 || c->post > 1 || (!resample && c->n_out != c->chunk_len))
+        return set_err(WH_E_ARG, "wh_chanbank_create: bad configuration");
+    for (int i = 0; i < c->n_stages; ++i)
+        if (c->h_stages[i].n < 1 || c->h_stages[i].n > MAX_ORD || c->h_stages[i].a[0] == 0.0)
+            return set_err(WH_E_ARG, "wh_chanbank_create: bad IIR stage %d", i);
+    wh_chanbank *b = new wh_chanbank();
     b->cfg = *c;
     b->cfg.h_offsets_hz = nullptr;
     b->cfg.h_taps = nullptr;
+    b->cfg.h_stages = nullptr;
+    b->post = c->post == 0 ? 0 : (c->agc ? 1 : 2);
     std::vector<float> nco(c->n_channels);
     for (int k = 0; k < c->n_channels; ++k) nco[k] = c->h_offsets_hz[k] == 0 ? 0.0f : nco_const(c->h_offsets_hz[k], c->sample_rate);
     WH_HIP(hipMalloc(&b->d_nco, nco.size() * sizeof(float)));
     WH_HIP(hipMemcpy(b->d_nco, nco.data(), nco.size() * sizeof(float), hipMemcpyHostToDevice));
-    WH_HIP(hipMalloc(&b->d_taps, (size_t)c->ntaps * sizeof(double)));
-    WH_HIP(hipMemcpy(b->d_taps, c->h_taps, (size_t)c->ntaps * sizeof(double), hipMemcpyHostToDevice));
-    if (c->mode == 1 && c->h_mpx_b && c->h_mpx_a) {
-        double ba[12];
-        for (int i = 0; i < 6; ++i) {
-            ba[i] = c->h_mpx_b[i] / c->h_mpx_a[0];
-            ba[6 + i] = c->h_mpx_a[i] / c->h_mpx_a[0];
-        }
-        WH_HIP(hipMalloc(&b->d_ba, sizeof(ba)));
-        WH_HIP(hipMemcpy(b->d_ba, ba, sizeof(ba), hipMemcpyHostToDevice));
+    if (resample) {
+        WH_HIP(hipMalloc(&b->d_taps, (size_t)c->ntaps * sizeof(double)));
+        WH_HIP(hipMemcpy(b->d_taps, c->h_taps, (size_t)c->ntaps * sizeof(double), hipMemcpyHostToDevice));
     }
-    // fused path: nbfm, pure decimation, everything fits in LDS
+    if (c->n_stages > 0) {
+        // normalise by a[0] in the stage's dtype, as lfilter does on its dtype-cast copies
+        std::vector<StageDev> sd(c->n_stages);
+        for (int i = 0; i < c->n_stages; ++i) {
+            const wh_iir_stage &h = c->h_stages[i];
+            sd[i].is_f64 = h.is_f64;
+            sd[i].n = h.n;
+            for (int k = 0; k < MAX_ORD; ++k) {
+                if (k >= h.n) { sd[i].b[k] = 0.0; sd[i].a[k] = 0.0; continue; }
+                if (h.is_f64) {
+                    sd[i].b[k] = h.b[k] / h.a[0];
+                    sd[i].a[k] = h.a[k] / h.a[0];
+                } else {
+                    sd[i].b[k] = (double)((float)h.b[k] / (float)h.a[0]);
+                    sd[i].a[k] = (double)((float)h.a[k] / (float)h.a[0]);
+                }
+            }
+        }
+        WH_HIP(hipMalloc(&b->d_stages, sd.size() * sizeof(StageDev)));
+        WH_HIP(hipMemcpy(b->d_stages, sd.data(), sd.size() * sizeof(StageDev), hipMemcpyHostToDevice));
+    }
+    // fused path: plain FM (no IIR stage, no AGC), pure decimation, everything fits in LDS
     b->fused = false;
-    if (c->mode == 0 && c->up == 1 && c->ntaps <= FM_MAX_TAPS) {
+    if (c->demod == 0 && c->n_stages == 0 && !c->agc && c->post == 0 && resample && c->up == 1 &&
+        c->ntaps <= FM_MAX_TAPS) {
         int TO = 256;
         while (TO > 8 && c->ntaps + (TO - 1) * c->down > FM_MAX_SPAN) TO >>= 1;
         if (c->ntaps + (TO - 1) * c->down <= FM_MAX_SPAN) {
@@ -506,17 +581,17 @@ extern "C" int wh_fmbank_create(wh_fmbank **out, const wh_fmbank_cfg *c) {
     return WH_OK;
 }
 
-extern "C" void wh_fmbank_destroy(wh_fmbank *b) {
+extern "C" void wh_chanbank_destroy(wh_chanbank *b) {
     if (!b) return;
     (void)hipFree(b->d_nco);
     (void)hipFree(b->d_taps);
-    (void)hipFree(b->d_ba);
+    (void)hipFree(b->d_stages);
     (void)hipFree(b->d_acc);
     (void)hipFree(b->d_fm);
     delete b;
 }
 
-extern "C" size_t wh_fmbank_workspace_bytes(const wh_fmbank *b, size_t n_chunks) {
+extern "C" size_t wh_chanbank_workspace_bytes(const wh_chanbank *b, size_t n_chunks) {
     if (!b) return 0;
     size_t rows = n_chunks * (size_t)b->cfg.n_channels;
     size_t bytes = rows * 2 * sizeof(double);
@@ -524,15 +599,16 @@ extern "C" size_t wh_fmbank_workspace_bytes(const wh_fmbank *b, size_t n_chunks)
     return bytes;
 }
 
-extern "C" int wh_fmbank_run(wh_fmbank *b, const void *d_in, size_t n_chunks, float *d_audio, float *d_metrics,
-                             void *stream) {
-    if (!b) return set_err(WH_E_ARG, "wh_fmbank_run: null handle");
+extern "C" int wh_chanbank_run(wh_chanbank *b, const void *d_in, size_t n_chunks, float *d_audio, float *d_metrics,
+                               void *stream) {
+    if (!b) return set_err(WH_E_ARG, "wh_chanbank_run: null handle");
     if (n_chunks == 0) return WH_OK;
-    if (!d_in || !d_audio || !d_metrics) return set_err(WH_E_ARG, "wh_fmbank_run: null buffer");
-    if (n_chunks > 65535) return set_err(WH_E_ARG, "wh_fmbank_run: n_chunks > 65535 per call");
+    if (!d_in || !d_audio || !d_metrics) return set_err(WH_E_ARG, "wh_chanbank_run: null buffer");
+    if (n_chunks > 65535) return set_err(WH_E_ARG, "wh_chanbank_run: n_chunks > 65535 per call");
     hipStream_t st = as_stream(stream);
-    const wh_fmbank_cfg &c = b->cfg;
+    const wh_chanbank_cfg &c = b->cfg;
     const size_t rows = n_chunks * (size_t)c.n_channels;
+    const bool resample = c.ntaps > 0;
     if (n_chunks > b->cap_chunks) {  // grow the workspace (synchronises; steady state never does)
         WH_HIP(hipStreamSynchronize(st));
         (void)hipFree(b->d_acc);
@@ -540,7 +616,7 @@ extern "C" int wh_fmbank_run(wh_fmbank *b, const void *d_in, size_t n_chunks, fl
         b->d_acc = nullptr;
         b->d_fm = nullptr;
         WH_HIP(hipMalloc(&b->d_acc, rows * 2 * sizeof(double)));
-        if (!b->fused) WH_HIP(hipMalloc(&b->d_fm, rows * (size_t)c.chunk_len * sizeof(float)));
+        if (!b->fused && resample) WH_HIP(hipMalloc(&b->d_fm, rows * (size_t)c.chunk_len * sizeof(float)));
         b->cap_chunks = n_chunks;
     }
     WH_HIP(hipMemsetAsync(b->d_acc, 0, rows * 2 * sizeof(double), st));
@@ -548,7 +624,7 @@ extern "C" int wh_fmbank_run(wh_fmbank *b, const void *d_in, size_t n_chunks, fl
     a.in = d_in;
     a.audio = d_audio;
     a.acc = b->d_acc;
-    a.fm_out = b->d_fm;
+    a.fm_out = resample ? b->d_fm : d_audio;   // no resampling: rows are the audio
     a.nco_c = b->d_nco;
     a.taps = b->d_taps;
     a.fmt = c.input_format;
@@ -560,6 +636,9 @@ extern "C" int wh_fmbank_run(wh_fmbank *b, const void *d_in, size_t n_chunks, fl
     a.d0 = c.d0;
     a.TO = b->TO;
     a.scale = (float)((double)c.sample_rate / (2.0 * M_PI * 75000.0));
+    a.demod = c.demod;
+    a.bfo_c = 2.0 * M_PI * c.bfo_hz;   // Python: (2j*np.pi) * offset_hz
+    a.fs_d = (double)c.sample_rate;
     if (b->fused) {
         int tiles = (c.n_out + b->TO - 1) / b->TO;
         hipLaunchKernelGGL(fmbank_fused_kernel, dim3(tiles, c.n_channels, (unsigned)n_chunks), dim3(256), b->smem, st, a);
@@ -567,20 +646,27 @@ extern "C" int wh_fmbank_run(wh_fmbank *b, const void *d_in, size_t n_chunks, fl
     } else {
         int per_block = 4 * 63 * 16;
         int blocks = (c.chunk_len + per_block - 1) / per_block;
-        hipLaunchKernelGGL(fmbank_disc_kernel, dim3(blocks, c.n_channels, (unsigned)n_chunks), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(chan_front_kernel, dim3(blocks, c.n_channels, (unsigned)n_chunks), dim3(256), 0, st, a);
         WH_LAUNCH_CHECK();
-        if (c.mode == 1) {
-            // float32 coefficient arrays of the reference: b=[alpha], a=[1, -(1-alpha)] (dsp/fm.py:106-107)
-            hipLaunchKernelGGL(wbfm_iir_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st, b->d_fm, b->d_acc,
-                               (int)rows, c.chunk_len, c.deemph_b0, -c.deemph_a1, b->d_ba, b->d_ba ? 1 : 0);
+        if (c.n_stages > 0 || c.agc) {
+            AgcDev g;
+            g.on = c.agc;
+            g.target = c.agc_target;
+            g.max_gain = c.agc_max_gain;
+            g.att_b0 = c.agc_att_b0; g.att_a1 = c.agc_att_a1;
+            g.rel_b0 = c.agc_rel_b0; g.rel_a1 = c.agc_rel_a1;
+            hipLaunchKernelGGL(chan_rows_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st, a.fm_out, b->d_acc,
+                               (int)rows, c.chunk_len, b->d_stages, c.n_stages, g);
             WH_LAUNCH_CHECK();
         }
-        int rc = launch_resample(b->d_fm, (size_t)c.chunk_len, rows, d_audio, (size_t)c.n_out, b->d_taps, c.ntaps, c.up,
-                                 c.down, c.d0, st);
-        if (rc != WH_OK) return rc;
+        if (resample) {
+            int rc = launch_resample(b->d_fm, (size_t)c.chunk_len, rows, d_audio, (size_t)c.n_out, b->d_taps, c.ntaps,
+                                     c.up, c.down, c.d0, st);
+            if (rc != WH_OK) return rc;
+        }
     }
     hipLaunchKernelGGL(fmbank_finalize_kernel, dim3((unsigned)rows), dim3(256), 0, st, d_audio, b->d_acc, d_metrics,
-                       c.chunk_len, c.n_out);
+                       c.chunk_len, c.n_out, b->post);
     WH_LAUNCH_CHECK();
     return WH_OK;
 }

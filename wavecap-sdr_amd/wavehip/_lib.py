@@ -30,24 +30,35 @@ lib = C.CDLL(LIB_PATH)
 c_void_p, c_int, c_size_t, c_float, c_double = C.c_void_p, C.c_int, C.c_size_t, C.c_float, C.c_double
 
 
-class FmBankCfg(C.Structure):
+class IirStage(C.Structure):
+    _fields_ = [("is_f64", c_int), ("n", c_int), ("b", c_double * 11), ("a", c_double * 11)]
+
+
+class ChanBankCfg(C.Structure):
     _fields_ = [
         ("sample_rate", c_int),
         ("chunk_len", c_int),
         ("n_channels", c_int),
         ("h_offsets_hz", C.POINTER(c_int)),
         ("input_format", c_int),
-        ("mode", c_int),
+        ("demod", c_int),
+        ("bfo_hz", c_double),
+        ("n_stages", c_int),
+        ("h_stages", C.POINTER(IirStage)),
+        ("agc", c_int),
+        ("agc_target", c_float),
+        ("agc_max_gain", c_float),
+        ("agc_att_b0", c_float),
+        ("agc_att_a1", c_float),
+        ("agc_rel_b0", c_float),
+        ("agc_rel_a1", c_float),
+        ("post", c_int),
         ("h_taps", C.POINTER(c_double)),
         ("ntaps", c_int),
         ("up", c_int),
         ("down", c_int),
         ("d0", c_int),
         ("n_out", c_int),
-        ("deemph_b0", c_float),
-        ("deemph_a1", c_float),
-        ("h_mpx_b", C.POINTER(c_double)),
-        ("h_mpx_a", C.POINTER(c_double)),
     ]
 
 
@@ -65,10 +76,10 @@ PROTOTYPES = {
     "wh_resampler_create": (c_int, [C.POINTER(c_void_p), C.POINTER(c_double), c_int, c_int, c_int, c_int]),
     "wh_resampler_run": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_size_t, c_void_p]),
     "wh_resampler_destroy": (None, [c_void_p]),
-    "wh_fmbank_create": (c_int, [C.POINTER(c_void_p), C.POINTER(FmBankCfg)]),
-    "wh_fmbank_run": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
-    "wh_fmbank_workspace_bytes": (c_size_t, [c_void_p, c_size_t]),
-    "wh_fmbank_destroy": (None, [c_void_p]),
+    "wh_chanbank_create": (c_int, [C.POINTER(c_void_p), C.POINTER(ChanBankCfg)]),
+    "wh_chanbank_run": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "wh_chanbank_workspace_bytes": (c_size_t, [c_void_p, c_size_t]),
+    "wh_chanbank_destroy": (None, [c_void_p]),
     "wh_pfb_create": (c_int, [C.POINTER(c_void_p), c_int, c_int, C.POINTER(c_double)]),
     "wh_pfb_hops": (c_size_t, [c_void_p, c_size_t]),
     "wh_pfb_run": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),

@@ -1,19 +1,22 @@
 """Channel operator: the batched MI355X form of capture.py:298-439
 `_process_channel_dsp_stateless(samples, sample_rate, cfg) -> (audio | None, metrics)`.
 
-`ChannelBank` runs all channels of one capture (and any number of consecutive
-chunks) in one launch: the IQ chunk is shared by every channel through L2, the NCO mix
-(capture.py:166-193), FM discriminator (dsp/fm.py:65-97), RMS normalise (fm.py:42-62),
-resample_poly (fm.py:184-221) and soft clip (fm.py:26-39) are fused on the device and the
-two metrics the lifecycle consumes (`rssi_db`, `signal_power_db`, capture.py:2579-2582)
-come back with the audio.
+`ChannelBank` runs all channels of one capture (and any number of consecutive chunks) in one
+launch: the IQ chunk is shared by every channel through L2; NCO mix (capture.py:166-193), the
+demodulator front (FM discriminator dsp/fm.py:65-97, AM envelope dsp/am.py:103, SSB product
+detector dsp/am.py:200-210), the optional IIR stages (de-emphasis, MPX / Butterworth / notch,
+dsp/fm.py:101-181, dsp/filters.py:86-264), AGC (dsp/agc.py:169-242), resample_poly
+(dsp/fm.py:184-221) and the soft clip run on the device, and the two metrics the lifecycle
+consumes (`rssi_db`, `signal_power_db`, capture.py:2579-2582) come back with the audio.  Every
+filter is designed here with the very scipy calls the reference makes, so coefficients are
+identical.
 
-`process_channel_dsp_stateless` is the single-channel drop-in with the reference's
-exact signature and error convention (non-finite input or audio failing
-validate_audio_samples -> (None, metrics); capture.py:323-325, 433-435).
-Supported modes: "nbfm", "wbfm" (mode defaults of capture.py:3425-3496).  Other
-modes raise NotImplementedError -- the integration stub keeps routing them to the
-reference implementation; nothing here falls back to a CPU path.
+`process_channel_dsp_stateless` is the single-channel drop-in with the reference's exact
+signature and error convention (non-finite input or audio failing validate_audio_samples ->
+(None, metrics); capture.py:323-325, 433-435).  Supported modes: "nbfm", "wbfm", "am", "ssb"
+with their filter flags.  "sam", "raw", digital modes and spectral noise reduction raise
+NotImplementedError -- the integration stub keeps routing those to the reference implementation
+(INTEGRATION.md); nothing here falls back to a CPU path.
 """
 
 from __future__ import annotations
@@ -36,8 +39,8 @@ AUDIO_MAX_ABS = 1.2  # validation.py:9
 
 @dataclass
 class ChannelConfig:
-    """Subset mirror of capture.py:442-501 (same field names; the reference's own
-    ChannelConfig instances are accepted as-is, this class exists for standalone use)."""
+    """Mirror of the DSP fields of capture.py:442-501 (same names and defaults; the reference's
+    own ChannelConfig instances are accepted as-is, this class exists for standalone use)."""
 
     id: str = "ch"
     capture_id: str = "cap"
@@ -49,7 +52,20 @@ class ChannelConfig:
     enable_mpx_filter: bool = True
     mpx_cutoff_hz: float = 15_000
     enable_fm_highpass: bool = False
+    fm_highpass_hz: float = 100
     enable_fm_lowpass: bool = False
+    fm_lowpass_hz: float = 3_000
+    enable_am_highpass: bool = True
+    am_highpass_hz: float = 100
+    enable_am_lowpass: bool = True
+    am_lowpass_hz: float = 5_000
+    enable_ssb_bandpass: bool = True
+    ssb_bandpass_low_hz: float = 300
+    ssb_bandpass_high_hz: float = 3_000
+    ssb_mode: str = "usb"
+    ssb_bfo_offset_hz: float = 1500.0
+    enable_agc: bool = False
+    agc_target_db: float = -20.0
     notch_frequencies: list = field(default_factory=list)
     enable_noise_reduction: bool = False
 
@@ -66,22 +82,120 @@ def resample_design(in_rate: int, out_rate: int):
 
 
 def _unsupported(cfg) -> str | None:
-    mode = cfg.mode
-    if mode not in ("nbfm", "wbfm"):
-        return f"mode {mode!r}"
-    if getattr(cfg, "notch_frequencies", None):
-        return "notch filters"
-    if getattr(cfg, "enable_noise_reduction", False):
+    if cfg.mode not in ("nbfm", "wbfm", "am", "ssb"):
+        return f"mode {cfg.mode!r}"
+    if getattr(cfg, "enable_noise_reduction", False) and cfg.mode in ("nbfm", "wbfm"):
         return "spectral noise reduction"
-    if getattr(cfg, "enable_fm_highpass", False) or getattr(cfg, "enable_fm_lowpass", False):
-        return "optional FM high/low-pass"
-    if mode == "nbfm" and getattr(cfg, "enable_deemphasis", False):
-        return "NBFM de-emphasis"
     return None
 
 
+def _stage(b, a, is_f64: bool):
+    b = np.atleast_1d(np.asarray(b, dtype=np.float64))
+    a = np.atleast_1d(np.asarray(a, dtype=np.float64))
+    n = max(len(b), len(a))
+    if n > 11:
+        raise NotImplementedError("IIR section longer than 11 coefficients")
+    st = _lib.IirStage()
+    st.is_f64, st.n = (1 if is_f64 else 0), n
+    for k in range(11):
+        st.b[k] = float(b[k]) if k < len(b) else 0.0
+        st.a[k] = float(a[k]) if k < len(a) else 0.0
+    return st
+
+
+def _butter(kind: str, sample_rate: int, cutoff):
+    """dsp/filters.py:86-221 validity rules + cached butter(5) design."""
+    nyq = sample_rate / 2.0
+    if kind == "band":
+        lo, hi = cutoff[0] / nyq, cutoff[1] / nyq
+        if lo <= 0 or hi >= 1.0 or lo >= hi:
+            return None
+        return signal.butter(5, [lo, hi], btype="band")
+    wn = cutoff / nyq
+    if wn <= 0 or wn >= 1.0:
+        return None
+    return signal.butter(5, wn, btype=kind)
+
+
+def _notches(cfg, sample_rate: int):
+    out = []
+    for f in getattr(cfg, "notch_frequencies", None) or []:
+        if 0 < f < sample_rate / 2:                     # dsp/fm.py:297-300
+            nf = f / (sample_rate / 2.0)
+            if 0 < nf < 1.0:                            # dsp/filters.py:252-254
+                out.append(_stage(*signal.iirnotch(nf, 30.0), True))
+    return out
+
+
+def build_chain(cfg, sample_rate: int):
+    """-> (demod, bfo_hz, stages, agc tuple | None, post) in the reference's application order."""
+    mode = cfg.mode
+    stages = []
+    agc = None
+    bfo = 0.0
+    if mode in ("nbfm", "wbfm"):
+        demod, post = 0, 0
+        if cfg.enable_deemphasis:                       # dsp/fm.py:101-126 (tau as integer microseconds)
+            tau = int((cfg.deemphasis_tau_us * 1e-6) * 1e6) * 1e-6
+            alpha = 1.0 / (1.0 + (1.0 / (2.0 * np.pi * tau * sample_rate)))
+            stages.append(_stage(np.array([alpha], np.float32), np.array([1.0, -(1.0 - alpha)], np.float32), False))
+        if mode == "wbfm" and cfg.enable_mpx_filter:    # dsp/fm.py:129-181
+            nc = int(cfg.mpx_cutoff_hz) / (sample_rate / 2.0)
+            if nc < 1.0:
+                stages.append(_stage(*signal.butter(5, nc, btype="low"), True))
+        if cfg.enable_fm_highpass and cfg.fm_highpass_hz > 0:
+            ba = _butter("high", sample_rate, cfg.fm_highpass_hz)
+            if ba is not None:
+                stages.append(_stage(*ba, True))
+        if mode == "nbfm" and cfg.enable_fm_lowpass and cfg.fm_lowpass_hz > 0:
+            ba = _butter("low", sample_rate, cfg.fm_lowpass_hz)
+            if ba is not None:
+                stages.append(_stage(*ba, True))
+        stages += _notches(cfg, sample_rate)
+    else:
+        post = 1
+        if mode == "am":                                # dsp/am.py:45-141
+            demod = 1
+            if cfg.enable_am_highpass and cfg.am_highpass_hz > 0:
+                ba = _butter("high", sample_rate, cfg.am_highpass_hz)
+                if ba is not None:
+                    stages.append(_stage(*ba, True))
+            if cfg.enable_am_lowpass and cfg.am_lowpass_hz > 0:
+                ba = _butter("low", sample_rate, cfg.am_lowpass_hz)
+                if ba is not None:
+                    stages.append(_stage(*ba, True))
+        else:                                           # dsp/am.py:144-247
+            demod = 2
+            bfo = cfg.ssb_bfo_offset_hz if cfg.ssb_mode.lower() == "usb" else -cfg.ssb_bfo_offset_hz
+            if cfg.enable_ssb_bandpass:
+                ba = _butter("band", sample_rate, (cfg.ssb_bandpass_low_hz, cfg.ssb_bandpass_high_hz))
+                if ba is not None:
+                    stages.append(_stage(*ba, True))
+        stages += _notches(cfg, sample_rate)
+        if cfg.enable_agc:                              # dsp/agc.py:169-242, attack 5 ms / release 50 ms
+            att = (5.0 / 1000.0) * sample_rate
+            rel = (50.0 / 1000.0) * sample_rate
+            ac = 1.0 - np.exp(-1.0 / att) if att > 0 else 1.0
+            rc = 1.0 - np.exp(-1.0 / rel) if rel > 0 else 1.0
+            agc = (np.float32(10.0 ** (cfg.agc_target_db / 20.0)), np.float32(10.0 ** (60.0 / 20.0)),
+                   np.float32(ac), np.float32(-(1.0 - ac)), np.float32(rc), np.float32(-(1.0 - rc)))
+    if len(stages) > 8:
+        raise NotImplementedError("more than 8 IIR sections in one channel")
+    return demod, float(bfo), stages, agc, post
+
+
+def _chain_key(cfg):
+    return (cfg.mode, int(cfg.audio_rate), bool(cfg.enable_deemphasis), float(cfg.deemphasis_tau_us),
+            bool(cfg.enable_mpx_filter), float(cfg.mpx_cutoff_hz), bool(cfg.enable_fm_highpass),
+            float(cfg.fm_highpass_hz), bool(cfg.enable_fm_lowpass), float(cfg.fm_lowpass_hz),
+            bool(cfg.enable_am_highpass), float(cfg.am_highpass_hz), bool(cfg.enable_am_lowpass),
+            float(cfg.am_lowpass_hz), bool(cfg.enable_ssb_bandpass), float(cfg.ssb_bandpass_low_hz),
+            float(cfg.ssb_bandpass_high_hz), str(cfg.ssb_mode), float(cfg.ssb_bfo_offset_hz),
+            bool(cfg.enable_agc), float(cfg.agc_target_db), tuple(getattr(cfg, "notch_frequencies", None) or ()))
+
+
 class ChannelBank:
-    """All channels of one capture, one mode, one audio rate."""
+    """All channels of one capture that share one chain (mode + filter settings + audio rate)."""
 
     def __init__(self, sample_rate: int, chunk_len: int, cfgs: list, input_format: str = "cf32"):
         if not cfgs:
@@ -90,57 +204,54 @@ class ChannelBank:
             why = _unsupported(c)
             if why:
                 raise NotImplementedError(f"wavehip ChannelBank: {why} is not implemented on the device")
-        modes = {c.mode for c in cfgs}
-        rates = {int(c.audio_rate) for c in cfgs}
-        if len(modes) != 1 or len(rates) != 1:
-            raise ValueError("ChannelBank: all channels must share mode and audio_rate (group them first)")
-        self.mode = modes.pop()
-        self.audio_rate = rates.pop()
+        if len({_chain_key(c) for c in cfgs}) != 1:
+            raise ValueError("ChannelBank: all channels must share mode, filter settings and audio_rate "
+                             "(group them first)")
+        c0 = cfgs[0]
+        self.mode = c0.mode
+        self.audio_rate = int(c0.audio_rate)
         self.sample_rate = int(sample_rate)
         self.chunk_len = int(chunk_len)
         self.cfgs = list(cfgs)
         self.K = len(cfgs)
         self.input_format = {"cf32": 0, "int16": 1}[input_format]
         self._torch = _lib.require_gpu()
-        if self.sample_rate == self.audio_rate:
-            raise NotImplementedError("ChannelBank: sample_rate == audio_rate (no resampling) is not implemented")
-        h, up, down, d0 = resample_design(self.sample_rate, self.audio_rate)
-        self.up, self.down = up, down
-        n_up = self.chunk_len * up
-        self.n_out = n_up // down + (1 if n_up % down else 0)
+        demod, bfo, stages, agc, post = build_chain(c0, self.sample_rate)
         offs = np.array([int(round(float(c.offset_hz))) if float(c.offset_hz) != 0.0 else 0 for c in cfgs],
                         dtype=np.int32)
-        cfg = _lib.FmBankCfg()
+        cfg = _lib.ChanBankCfg()
         cfg.sample_rate, cfg.chunk_len, cfg.n_channels = self.sample_rate, self.chunk_len, self.K
         cfg.h_offsets_hz = _lib.dptr(offs, "i32")
         cfg.input_format = self.input_format
-        cfg.mode = 0 if self.mode == "nbfm" else 1
-        cfg.h_taps = _lib.dptr(h, "f64")
-        cfg.ntaps, cfg.up, cfg.down, cfg.d0, cfg.n_out = len(h), up, down, d0, self.n_out
-        keep = [offs, h]
-        cfg.deemph_b0, cfg.deemph_a1 = 0.0, 0.0
-        if self.mode == "wbfm":
-            c0 = cfgs[0]
-            for c in cfgs:
-                if (c.enable_deemphasis, c.deemphasis_tau_us, c.enable_mpx_filter, c.mpx_cutoff_hz) != \
-                        (c0.enable_deemphasis, c0.deemphasis_tau_us, c0.enable_mpx_filter, c0.mpx_cutoff_hz):
-                    raise ValueError("ChannelBank(wbfm): channels must share the de-emphasis / MPX settings")
-            if c0.enable_deemphasis:  # dsp/fm.py:101-108 (tau quantised to integer microseconds)
-                tau = int((c0.deemphasis_tau_us * 1e-6) * 1e6) * 1e-6
-                alpha = 1.0 / (1.0 + (1.0 / (2.0 * np.pi * tau * self.sample_rate)))
-                cfg.deemph_b0 = float(np.float32(alpha))
-                cfg.deemph_a1 = float(np.float32(-(1.0 - alpha)))
-            if c0.enable_mpx_filter:  # dsp/fm.py:129-144
-                nc = int(c0.mpx_cutoff_hz) / (self.sample_rate / 2.0)
-                if nc < 1.0:
-                    b, a = signal.butter(5, nc, btype="low")
-                    b = np.ascontiguousarray(b, dtype=np.float64)
-                    a = np.ascontiguousarray(a, dtype=np.float64)
-                    cfg.h_mpx_b, cfg.h_mpx_a = _lib.dptr(b, "f64"), _lib.dptr(a, "f64")
-                    keep += [b, a]
+        cfg.demod, cfg.bfo_hz, cfg.post = demod, bfo, post
+        keep = [offs]
+        cfg.n_stages = len(stages)
+        if stages:
+            arr = (_lib.IirStage * len(stages))(*stages)
+            cfg.h_stages = arr
+            keep.append(arr)
+        cfg.agc = 1 if agc is not None else 0
+        if agc is not None:
+            (cfg.agc_target, cfg.agc_max_gain, cfg.agc_att_b0, cfg.agc_att_a1, cfg.agc_rel_b0,
+             cfg.agc_rel_a1) = (float(v) for v in agc)
+        if self.sample_rate == self.audio_rate:         # dsp/fm.py:198-199: no resampling
+            self.up = self.down = 1
+            self.n_out = self.chunk_len
+            cfg.ntaps = 0
+            cfg.up = cfg.down = 1
+            cfg.d0 = 0
+        else:
+            h, up, down, d0 = resample_design(self.sample_rate, self.audio_rate)
+            keep.append(h)
+            self.up, self.down = up, down
+            n_up = self.chunk_len * up
+            self.n_out = n_up // down + (1 if n_up % down else 0)
+            cfg.h_taps = _lib.dptr(h, "f64")
+            cfg.ntaps, cfg.up, cfg.down, cfg.d0 = len(h), up, down, d0
+        cfg.n_out = self.n_out
         self._h = C.c_void_p()
-        self._destroy = _lib.lib.wh_fmbank_destroy
-        _lib.check(_lib.lib.wh_fmbank_create(C.byref(self._h), C.byref(cfg)), "wh_fmbank_create")
+        self._destroy = _lib.lib.wh_chanbank_destroy
+        _lib.check(_lib.lib.wh_chanbank_create(C.byref(self._h), C.byref(cfg)), "wh_chanbank_create")
         del keep
 
     def __del__(self):
@@ -162,8 +273,8 @@ class ChannelBank:
             audio = torch.empty((n_chunks, self.K, self.n_out), dtype=torch.float32, device=d_in.device)
         if metrics is None:
             metrics = torch.empty((n_chunks, self.K, 4), dtype=torch.float32, device=d_in.device)
-        _lib.check(_lib.lib.wh_fmbank_run(self._h, d_in.data_ptr(), n_chunks, audio.data_ptr(), metrics.data_ptr(),
-                                          _lib.stream_ptr(torch)), "wh_fmbank_run")
+        _lib.check(_lib.lib.wh_chanbank_run(self._h, d_in.data_ptr(), n_chunks, audio.data_ptr(), metrics.data_ptr(),
+                                            _lib.stream_ptr(torch)), "wh_chanbank_run")
         return audio, metrics
 
     def process(self, samples) -> list[tuple[np.ndarray | None, dict[str, Any]]]:
@@ -198,16 +309,14 @@ _bank_cache: dict[tuple, ChannelBank] = {}
 
 def process_channel_dsp_stateless(samples, sample_rate: int, cfg) -> tuple[np.ndarray | None, dict[str, Any]]:
     """Drop-in for capture.py:298 (single channel).  Banks are cached per
-    (rate, chunk length, mode, offset, audio rate, filter settings)."""
+    (rate, chunk length, offset, chain settings)."""
     metrics: dict[str, Any] = {}
     if samples.size == 0:
         return None, metrics
     why = _unsupported(cfg)
     if why:
         raise NotImplementedError(f"wavehip: {why} is not implemented on the device")
-    key = (int(sample_rate), int(samples.shape[0]), cfg.mode, int(round(float(cfg.offset_hz))), int(cfg.audio_rate),
-           bool(cfg.enable_deemphasis), float(cfg.deemphasis_tau_us), bool(cfg.enable_mpx_filter),
-           float(cfg.mpx_cutoff_hz))
+    key = (int(sample_rate), int(samples.shape[0]), int(round(float(cfg.offset_hz)))) + _chain_key(cfg)
     bank = _bank_cache.get(key)
     if bank is None:
         if len(_bank_cache) >= 64:
