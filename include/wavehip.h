@@ -148,6 +148,28 @@ void wh_spectrum_destroy(wh_spectrum *s);
 
 void wh_pfb_destroy(wh_pfb *p);
 
+/* ---- A4/A5: trunking front-end: phase-continuous float64-phase NCO
+ * (trunking/system.py:1434-1466) + two-stage decimating FIR (system.py:1392-1406, 1753-1779;
+ * dsp/filters.py:558-646 fir_decimate), kept outputs only.  h_taps*: float64 firwin designs;
+ * decim2 <= 1 -> single stage.  run(): d_iq complex64[n] -> d_out complex64[wh_ddc_out_len(n)];
+ * offset_hz == 0 skips the mix; a changed offset restarts the phase (system.py:1450-1452);
+ * the filter state (input history; first call = lfilter_zi * x[0]) and the sample index
+ * (wrapped at one second) are carried; reset() == the overflow recovery of system.py:1574-1588. */
+typedef struct wh_ddc wh_ddc;
+int wh_ddc_create(wh_ddc **out, int sample_rate, const double *h_taps1, int ntaps1, int decim1,
+                  const double *h_taps2, int ntaps2, int decim2, int max_samples_per_call);
+size_t wh_ddc_out_len(const wh_ddc *d, size_t n);
+int wh_ddc_run(wh_ddc *d, const float *d_iq, size_t n, double offset_hz, float *d_out, void *stream);
+int wh_ddc_reset(wh_ddc *d);
+void wh_ddc_destroy(wh_ddc *d);
+
+/* ---- A13: control-channel scanner measurement, trunking/cc_scanner.py:165-264 --------------
+ * For each candidate offset (already round()ed, 0 = no mix): capture.freq_shift ->
+ * lfilter(h_taps float64, zero state) -> [::decim] -> h_out[i] = {mean |y|^2, max |y|^2}
+ * (float64).  Synchronous: the scanner consumes the numbers on the host.                   */
+int wh_scan_measure(const float *d_iq, size_t n, int sample_rate, const int *h_offsets_hz, int n_offsets,
+                    const double *h_taps, int ntaps, int decim, double *h_out, void *stream);
+
 /* ---- A9-A11: P25 C4FM demodulator bank, dsp/p25/c4fm.py:2379-2807 ------------------
  * One independent C4FMDemodulator per channel (ctor c4fm.py:2412-2503).  Filters are
  * designed by the host exactly as the reference does (remez / RRC) and passed in.

@@ -269,7 +269,76 @@ def gen_c4fm():
     np.save(os.path.join(REPO, "wavecap-sdr_amd", "wavehip", "data", "mmse_interp_taps_f32.npy"), taps)
 
 
-ALL = dict(a1=gen_a1, a2=gen_a2, a3=gen_a3, a6=gen_a6, chain=gen_chain, a7=gen_a7, a8=gen_a8, c4fm=gen_c4fm)
+def gen_trunk():
+    """A4/A5 (control-channel IQ path of trunking/system.py:1735-1779) and A13 (cc_scanner)."""
+    from scipy import signal as ss
+    from wavecapsdr.dsp.filters import fir_decimate
+    from wavecapsdr.trunking.cc_scanner import ControlChannelScanner
+
+    out = {}
+    fs, d1, d2 = 2_400_000, 10, 5
+    t1 = ss.firwin(157, 0.8 / d1, window=("kaiser", 7.857))
+    t2 = ss.firwin(73, 0.8 / d2, window=("kaiser", 7.857))
+    z1t = ss.lfilter_zi(t1, 1.0).astype(np.complex128)
+    z2t = ss.lfilter_zi(t2, 1.0).astype(np.complex128)
+    # the NCO lives in a closure (system.py:1434-1466); its arithmetic is restated line by line here
+    state = dict(idx=0, last=0.0, z1=None, z2=None)
+
+    def nco(iq, off):
+        if off == 0.0 or iq.size == 0:
+            return iq
+        if off != state["last"]:
+            state["idx"] = 0
+            state["last"] = off
+        n = np.arange(iq.size, dtype=np.float64) + state["idx"]
+        phase = -2.0 * np.pi * off * n / fs
+        shift = np.exp(1j * phase).astype(np.complex64)
+        y = np.asarray(iq.astype(np.complex64, copy=False) * shift, dtype=np.complex64)
+        state["idx"] += iq.size
+        if state["idx"] >= fs:
+            state["idx"] %= fs
+        return y
+
+    lens = [120000, 120000, 99991, 120000, 50, 120000]     # ragged + a tiny call; > 1 s in total wraps the index
+    offs = [312500.0, 312500.0, 312500.0, -100000.0, -100000.0, -100000.0]
+    x = S.c4fm_iq(sum(lens), fs, 1200, snr_db=25.0, freq_offset_hz=312500.0)[0]
+    pos = 0
+    outs = []
+    for n, off in zip(lens, offs):
+        c = nco(x[pos:pos + n], off)
+        pos += n
+        if state["z1"] is None:
+            state["z1"] = z1t * c[0]
+        y1, state["z1"] = fir_decimate(c, t1, d1, zi=state["z1"])
+        if state["z2"] is None:
+            state["z2"] = z2t * y1[0]
+        y2, state["z2"] = fir_decimate(y1, t2, d2, zi=state["z2"])
+        outs.append(np.asarray(y2, dtype=np.complex64))
+    out["ddc_args"] = np.array([fs, d1, d2, 1200], dtype=np.int64)
+    out["ddc_lens"] = np.array(lens, dtype=np.int64)
+    out["ddc_offs"] = np.array(offs)
+    out["ddc_sha"] = np.array(S.sha256(x))
+    out["ddc_out"] = np.concatenate(outs)
+    out["ddc_counts"] = np.array([len(o) for o in outs], dtype=np.int64)
+    # scanner: 3 carriers in a 2.4 MS/s buffer
+    n = 240000
+    center = 415.0e6
+    chans = [center + 300e3, center - 450e3, center + 812.5e3, center + 50e3]
+    t = np.arange(n) / fs
+    rng = np.random.default_rng(77)
+    w = (0.2 * np.exp(2j * np.pi * 300e3 * t) + 0.05 * np.exp(2j * np.pi * -450e3 * t)
+         + 0.01 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64)
+    sc = ControlChannelScanner(center_hz=center, sample_rate=fs, control_channels=chans, sync_check_enabled=False)
+    meas = [sc._measure_channel(w, f) for f in chans]
+    out["scan_sha"] = np.array(S.sha256(w))
+    out["scan_args"] = np.array([fs, n, 77], dtype=np.int64)
+    out["scan_offsets"] = np.array([f - center for f in chans])
+    out["scan_meas"] = np.array([[m.power_db, m.peak_power_db, m.noise_floor_db, m.snr_db, m.sample_count]
+                                 for m in meas])
+    save("trunk", **out)
+
+
+ALL = dict(trunk=gen_trunk, a1=gen_a1, a2=gen_a2, a3=gen_a3, a6=gen_a6, chain=gen_chain, a7=gen_a7, a8=gen_a8, c4fm=gen_c4fm)
 
 if __name__ == "__main__":
     import logging

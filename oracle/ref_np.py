@@ -531,3 +531,94 @@ def pfb_channel_stats(out: np.ndarray) -> np.ndarray:
     p = (out.real.astype(np.float64) ** 2 + out.imag.astype(np.float64) ** 2)
     H = p.shape[0]
     return np.stack([p.sum(0), (p * p).sum(0), np.full(p.shape[1], float(H)), p.min(0), p.max(0)], axis=1)
+
+
+# --------------------------------------------------------------------------
+# A4 / A5  trunking front-end: phase-continuous NCO + two-stage FIR decimation
+# --------------------------------------------------------------------------
+
+
+class TrunkingDDC:
+    """trunking/system.py:1392-1466, 1735-1779 with dsp/filters.py:558-646 (scipy fallback path):
+    float64-phase NCO continued across calls (index wrapped at one second), each stage
+    lfilter(float64 taps) on complex128 with carried state (first call: lfilter_zi * x[0]),
+    rounded to complex64, then [::D] restarting at index 0 every call."""
+
+    def __init__(self, sample_rate: int, stage1_factor: int, stage2_factor: int = 1):
+        self.fs = int(sample_rate)
+        self.d1, self.d2 = int(stage1_factor), int(stage2_factor)
+        self.t1 = _sig.firwin(157, 0.8 / self.d1, window=("kaiser", 7.857))
+        self.t2 = _sig.firwin(73, 0.8 / self.d2, window=("kaiser", 7.857)) if self.d2 > 1 else None
+        self.reset()
+
+    def reset(self):
+        self.h1 = None      # last len(t1)-1 mixed inputs (equivalent to the carried zi)
+        self.h2 = None
+        self.idx = 0
+        self.last_off = 0.0
+
+    @staticmethod
+    def _stage(x, taps, hist, D):
+        L = len(taps)
+        if hist is None:
+            hist = np.full(L - 1, x[0], dtype=np.complex128)     # lfilter_zi(taps) * x[0]
+        ext = np.concatenate([hist, x.astype(np.complex128)])
+        y = np.convolve(ext, taps.astype(np.float64))[L - 1: L - 1 + len(x)]
+        return y.astype(np.complex64)[::D], ext[len(ext) - (L - 1):]
+
+    def process(self, iq: np.ndarray, offset_hz: float) -> np.ndarray:
+        if iq.size == 0:
+            return iq
+        if offset_hz == 0.0:
+            c = iq
+        else:
+            if offset_hz != self.last_off:
+                self.idx = 0
+                self.last_off = offset_hz
+            n = np.arange(iq.size, dtype=np.float64) + self.idx
+            phase = -2.0 * np.pi * offset_hz * n / self.fs
+            c = (iq.astype(np.complex64, copy=False) * np.exp(1j * phase).astype(np.complex64)).astype(np.complex64)
+            self.idx += iq.size
+            if self.idx >= self.fs:
+                self.idx %= self.fs
+        y, self.h1 = self._stage(c, self.t1, self.h1, self.d1)
+        if self.t2 is not None and y.size > 0:
+            y, self.h2 = self._stage(y, self.t2, self.h2, self.d2)
+        return y
+
+
+# --------------------------------------------------------------------------
+# A13  control-channel scanner measurement (trunking/cc_scanner.py:165-264)
+# --------------------------------------------------------------------------
+
+
+def scanner_power(iq: np.ndarray, sample_rate: int, offsets_hz) -> np.ndarray:
+    """Per offset: freq_shift -> lfilter(firwin(65, 0.8/D, kaiser 6.0)) (zero state, complex128)
+    -> [::D] -> (mean |y|^2, max |y|^2)."""
+    D = max(1, sample_rate // 48000)
+    taps = _sig.firwin(65, 0.8 / D, window=("kaiser", 6.0)) if D > 1 else None
+    out = np.zeros((len(offsets_hz), 2))
+    for i, off in enumerate(offsets_hz):
+        s = freq_shift(iq, float(off), sample_rate)
+        if taps is not None:
+            y = np.convolve(s.astype(np.complex128), taps)[: len(s)][::D]
+        else:
+            y = s
+        p = np.abs(y) ** 2
+        out[i] = (np.mean(p), np.max(p))
+    return out
+
+
+def scanner_measure(iq: np.ndarray, sample_rate: int, channel_offsets_hz) -> list:
+    max_offset = sample_rate / 2 - 15000
+    edges = [-max_offset + 25000, max_offset - 25000]
+    p = scanner_power(iq, sample_rate, list(channel_offsets_hz) + edges)
+    noise = min(p[-2, 0], p[-1, 0])
+    eps = 1e-12
+    res = []
+    for i in range(len(channel_offsets_hz)):
+        pw = 10 * np.log10(p[i, 0] + eps)
+        nf = 10 * np.log10(noise + eps)
+        res.append(dict(power_db=float(pw), peak_power_db=float(10 * np.log10(p[i, 1] + eps)),
+                        noise_floor_db=float(nf), snr_db=float(pw - nf)))
+    return res

@@ -313,3 +313,42 @@ def test_a13_channel_stats(wh, O):
     assert np.allclose(st, ref, rtol=1e-9, atol=0)
     st2 = ch.channel_stats_device(y, torch.from_numpy(st.copy()).cuda(), accumulate=True).cpu().numpy()
     assert np.allclose(st2[:, :3], 2 * ref[:, :3], rtol=1e-9) and np.allclose(st2[:, 3:], ref[:, 3:], rtol=1e-12)
+
+
+def test_a4_a5_trunking_ddc(wh, golden, O):
+    """Phase-continuous NCO + two-stage decimator: reference golden (ragged calls, offset change,
+    index wrap) and a second seed against the oracle."""
+    g = golden("trunk")
+    fs, d1, d2, seed = (int(v) for v in g["ddc_args"])
+    lens, offs = [int(v) for v in g["ddc_lens"]], [float(v) for v in g["ddc_offs"]]
+    x = S.c4fm_iq(sum(lens), fs, seed, snr_db=25.0, freq_offset_hz=312500.0)[0]
+    ddc = wh.TrunkingDDC(fs, d1, d2)
+    assert (ddc.stage1_factor, ddc.stage2_factor) == wh.decimation_plan(fs) == (d1, d2)
+    pos, outs = 0, []
+    for n, off in zip(lens, offs):
+        outs.append(ddc.process(x[pos:pos + n], off))
+        pos += n
+    assert [len(o) for o in outs] == [int(v) for v in g["ddc_counts"]]
+    assert peak_rel_err(np.concatenate(outs), g["ddc_out"]) <= TOL
+    # reset() + no-mix path vs the oracle, single stage
+    x2 = S.noise_c64(300000, 9)
+    a, b = wh.TrunkingDDC(1_000_000, 20, 1), O.TrunkingDDC(1_000_000, 20, 1)
+    for part in (x2[:100000], x2[100000:100007], x2[100007:]):
+        assert peak_rel_err(a.process(part, 0.0), b.process(part, 0.0)) <= TOL
+    a.reset(); b.reset()
+    assert peak_rel_err(a.process(x2[:5000], 12345.0), b.process(x2[:5000], 12345.0)) <= TOL
+
+
+def test_a13_scanner_measure(wh, golden, O):
+    from test_oracle_golden import _scan_buffer
+
+    g = golden("trunk")
+    fs, n, seed = (int(v) for v in g["scan_args"])
+    w = _scan_buffer(n, fs, seed)
+    res = wh.ScannerMeasure(fs).measure(w, [float(v) for v in g["scan_offsets"]])
+    got = np.array([[m["power_db"], m["peak_power_db"], m["noise_floor_db"], m["snr_db"], m["sample_count"]]
+                    for m in res])
+    assert np.allclose(got[:, :4], g["scan_meas"][:, :4], atol=2e-4)
+    assert np.array_equal(got[:, 4], g["scan_meas"][:, 4])
+    order = np.argsort(-got[:, 3])
+    assert order[0] == 0 and order[1] == 1            # the two carriers rank first by SNR

@@ -94,6 +94,14 @@ PROTOTYPES = {
     "wh_spectrum_create": (c_int, [C.POINTER(c_void_p), c_int]),
     "wh_spectrum_run": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p]),
     "wh_spectrum_destroy": (None, [c_void_p]),
+    "wh_ddc_create": (c_int, [C.POINTER(c_void_p), c_int, C.POINTER(c_double), c_int, c_int, C.POINTER(c_double),
+                              c_int, c_int, c_int]),
+    "wh_ddc_out_len": (c_size_t, [c_void_p, c_size_t]),
+    "wh_ddc_run": (c_int, [c_void_p, c_void_p, c_size_t, c_double, c_void_p, c_void_p]),
+    "wh_ddc_reset": (c_int, [c_void_p]),
+    "wh_ddc_destroy": (None, [c_void_p]),
+    "wh_scan_measure": (c_int, [c_void_p, c_size_t, c_int, C.POINTER(c_int), c_int, C.POINTER(c_double), c_int, c_int,
+                                C.POINTER(c_double), c_void_p]),
     "wh_c4fm_bank_create": (c_int, [C.POINTER(c_void_p), c_int, c_double, C.POINTER(c_float), c_int,
                                     C.POINTER(c_float), c_int, C.POINTER(c_float), c_int]),
     "wh_c4fm_bank_run": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p, c_size_t,

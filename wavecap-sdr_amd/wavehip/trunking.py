@@ -1,0 +1,131 @@
+"""Trunking front-end operators on the MI355X.
+
+`TrunkingDDC`  -- the control-channel IQ path of trunking/system.py:1735-1779: phase-continuous
+                  NCO (system.py:1434-1466) + two-stage FIR decimation (system.py:1318-1406,
+                  dsp/filters.py:613-646), computing kept outputs only.
+`ScannerMeasure` -- ControlChannelScanner._measure_channel (trunking/cc_scanner.py:165-264):
+                  per-candidate power / peak / edge-noise / SNR, all candidates in one launch.
+Filter designs are the reference's own scipy calls."""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+from scipy import signal
+
+from . import _lib
+
+
+def decimation_plan(input_rate: int, target_output_rate: int = 48000) -> tuple[int, int]:
+    """Stage factors exactly as trunking/system.py:1310-1345."""
+    total = max(1, input_rate // target_output_rate)
+    s1f, s2f = total, 1
+    if total >= 48:
+        for s1 in [30, 24, 20, 16, 12, 10, 8]:
+            if total % s1 == 0 and 2 <= total // s1 <= 10:
+                s1f, s2f = s1, total // s1
+                break
+        else:
+            s1f = int(total ** 0.5)
+            s2f = total // s1f
+    else:
+        for s1 in [12, 10, 8, 6, 4]:
+            if total % s1 == 0 and 2 <= total // s1 <= 10:
+                s1f, s2f = s1, total // s1
+                break
+        else:
+            s1f, s2f = total, 1
+    return s1f, s2f
+
+
+class TrunkingDDC:
+    def __init__(self, sample_rate: int, stage1_factor: int | None = None, stage2_factor: int | None = None,
+                 max_samples_per_call: int = 1 << 20):
+        self._torch = _lib.require_gpu()
+        self.sample_rate = int(sample_rate)
+        if stage1_factor is None:
+            stage1_factor, stage2_factor = decimation_plan(self.sample_rate)
+        self.stage1_factor, self.stage2_factor = int(stage1_factor), int(stage2_factor or 1)
+        # system.py:1392-1406
+        self.stage1_taps = signal.firwin(157, 0.8 / self.stage1_factor, window=("kaiser", 7.857))
+        self.stage2_taps = (signal.firwin(73, 0.8 / self.stage2_factor, window=("kaiser", 7.857))
+                            if self.stage2_factor > 1 else np.zeros(1))
+        self.output_rate = self.sample_rate // self.stage1_factor // self.stage2_factor
+        t1 = np.ascontiguousarray(self.stage1_taps, dtype=np.float64)
+        t2 = np.ascontiguousarray(self.stage2_taps, dtype=np.float64)
+        self._h = C.c_void_p()
+        self._destroy = _lib.lib.wh_ddc_destroy
+        _lib.check(_lib.lib.wh_ddc_create(C.byref(self._h), self.sample_rate, _lib.dptr(t1, "f64"), len(t1),
+                                          self.stage1_factor, _lib.dptr(t2, "f64"), len(t2), self.stage2_factor,
+                                          int(max_samples_per_call)), "wh_ddc_create")
+
+    def __del__(self):
+        h, destroy = getattr(self, "_h", None), getattr(self, "_destroy", None)
+        if h and destroy:
+            destroy(h)
+            self._h = None
+
+    def reset(self) -> None:
+        _lib.check(_lib.lib.wh_ddc_reset(self._h), "wh_ddc_reset")
+
+    def out_len(self, n: int) -> int:
+        return int(_lib.lib.wh_ddc_out_len(self._h, n))
+
+    def process_device(self, iq_dev, offset_hz: float):
+        torch = self._torch
+        assert iq_dev.is_cuda and iq_dev.dtype == torch.complex64 and iq_dev.is_contiguous()
+        n = iq_dev.numel()
+        out = torch.empty(self.out_len(n), dtype=torch.complex64, device=iq_dev.device)
+        _lib.check(_lib.lib.wh_ddc_run(self._h, iq_dev.data_ptr(), n, float(offset_hz), out.data_ptr(),
+                                       _lib.stream_ptr(torch)), "wh_ddc_run")
+        return out
+
+    def process(self, iq, offset_hz: float) -> np.ndarray:
+        x = np.ascontiguousarray(iq, dtype=np.complex64)
+        if x.size == 0:
+            return x
+        return self.process_device(self._torch.from_numpy(x).cuda(), offset_hz).cpu().numpy()
+
+
+class ScannerMeasure:
+    """cc_scanner.py:165-264 for a list of candidate offsets of one wideband buffer."""
+
+    def __init__(self, sample_rate: int):
+        self._torch = _lib.require_gpu()
+        self.sample_rate = int(sample_rate)
+        self.decim = max(1, self.sample_rate // 48000)
+        self.taps = np.ascontiguousarray(
+            signal.firwin(65, 0.8 / self.decim, window=("kaiser", 6.0)) if self.decim > 1 else np.ones(1),
+            dtype=np.float64)
+
+    def power(self, iq_dev, offsets_hz) -> np.ndarray:
+        """-> float64 [n, 2] = (mean |y|^2, max |y|^2) per offset."""
+        torch = self._torch
+        assert iq_dev.is_cuda and iq_dev.dtype == torch.complex64 and iq_dev.is_contiguous()
+        offs = np.array([int(round(float(o))) if float(o) != 0.0 else 0 for o in offsets_hz], dtype=np.int32)
+        out = np.zeros((len(offs), 2), dtype=np.float64)
+        _lib.check(_lib.lib.wh_scan_measure(iq_dev.data_ptr(), iq_dev.numel(), self.sample_rate, _lib.dptr(offs, "i32"),
+                                            len(offs), _lib.dptr(self.taps, "f64"), len(self.taps), self.decim,
+                                            out.ctypes.data_as(C.POINTER(C.c_double)), _lib.stream_ptr(torch)),
+                   "wh_scan_measure")
+        return out
+
+    def measure(self, iq, channel_offsets_hz) -> list[dict]:
+        """Per candidate: power_db, peak_power_db, noise_floor_db, snr_db, sample_count -- the fields of
+        ChannelMeasurement (cc_scanner.py:240-264); sync detection is not part of this operator."""
+        torch = self._torch
+        x = iq if torch.is_tensor(iq) else torch.from_numpy(np.ascontiguousarray(iq, dtype=np.complex64)).cuda()
+        max_offset = self.sample_rate / 2 - 15000
+        edges = [-max_offset + 25000, max_offset - 25000]
+        p = self.power(x, list(channel_offsets_hz) + edges)
+        noise = min(p[-2, 0], p[-1, 0])
+        eps = 1e-12
+        out = []
+        for i in range(len(channel_offsets_hz)):
+            pw = 10 * np.log10(p[i, 0] + eps)
+            nf = 10 * np.log10(noise + eps)
+            out.append(dict(power_db=float(pw), peak_power_db=float(10 * np.log10(p[i, 1] + eps)),
+                            noise_floor_db=float(nf), snr_db=float(pw - nf),
+                            sample_count=(x.numel() + self.decim - 1) // self.decim))
+        return out
