@@ -187,6 +187,30 @@ int wh_c4fm_bank_run(wh_c4fm_bank *b, const float *d_iq, size_t n, size_t iq_str
 int wh_c4fm_bank_reset(wh_c4fm_bank *b, void *stream);
 void wh_c4fm_bank_destroy(wh_c4fm_bank *b);
 
+/* ---- A12: P25 Phase-2 CQPSK bank, dsp/p25/cqpsk.py:199-350 + dsp/p25/symbol_timing.py -------
+ * RRC matched filter (h_rrc float32 = design_rrc_filter_phase2, h_zi = lfilter_zi(rrc, 1.0)),
+ * Costas loop (c_kp, c_ki, c_maxf; cqpsk.py:94-119), Mueller-Muller timing (t_kp, t_ki;
+ * symbol_timing.py:238-270), pi/4-DQPSK differential decode.  All float64 like the reference.
+ * run(): d_iq complex64 [C][iq_stride] -> d_dibits uint8 [C][cap]; d_symbols (optional, may be
+ * NULL) complex128 [C][cap]; d_counts int32 [C].  State carried on the device.              */
+typedef struct wh_cqpsk_bank wh_cqpsk_bank;
+int wh_cqpsk_bank_create(wh_cqpsk_bank **out, int n_channels, double samples_per_symbol, const float *h_rrc,
+                         int ntaps, const double *h_zi, double c_kp, double c_ki, double c_maxf, double t_kp,
+                         double t_ki, int max_samples_per_call);
+int wh_cqpsk_bank_run(wh_cqpsk_bank *b, const float *d_iq, size_t n, size_t iq_stride, uint8_t *d_dibits,
+                      double *d_symbols, size_t cap, int32_t *d_counts, void *stream);
+int wh_cqpsk_bank_reset(wh_cqpsk_bank *b, void *stream);
+void wh_cqpsk_bank_destroy(wh_cqpsk_bank *b);
+
+/* Gardner timing error detector bank, dsp/p25/symbol_timing.py:60-211 (GardnerTED.process_block):
+ * d_x float32 [C][stride] -> d_symbols / d_errors float64 [C][cap], d_counts int32 [C].       */
+typedef struct wh_gardner_bank wh_gardner_bank;
+int wh_gardner_bank_create(wh_gardner_bank **out, int n_channels, double samples_per_symbol, double kp, double ki);
+int wh_gardner_bank_run(wh_gardner_bank *g, const float *d_x, size_t n, size_t stride, double *d_symbols,
+                        double *d_errors, size_t cap, int32_t *d_counts, void *stream);
+int wh_gardner_bank_reset(wh_gardner_bank *g, void *stream);
+void wh_gardner_bank_destroy(wh_gardner_bank *g);
+
 #ifdef __cplusplus
 }
 #endif

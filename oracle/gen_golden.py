@@ -338,7 +338,50 @@ def gen_trunk():
     save("trunk", **out)
 
 
-ALL = dict(trunk=gen_trunk, a1=gen_a1, a2=gen_a2, a3=gen_a3, a6=gen_a6, chain=gen_chain, a7=gen_a7, a8=gen_a8, c4fm=gen_c4fm)
+def gen_cqpsk():
+    """A12: Phase-2 CQPSK chain (dsp/p25/cqpsk.py) and the standalone GardnerTED."""
+    from wavecapsdr.dsp.p25.cqpsk import CQPSKDemodulator as RefCQPSK
+    from wavecapsdr.dsp.p25.symbol_timing import GardnerTED
+
+    out = {}
+    cases = [(48000, 12000, 24000, 1501, 25.0, 40.0), (48000, 12000, 24000, 1502, 12.0, -150.0),
+             (96000, 12000, 24000, 1503, 30.0, 10.0)]
+    for ci, (fs, sr, n, seed, snr, foff) in enumerate(cases):
+        iq, _ = S.dqpsk_iq(n, fs, seed, symbol_rate=sr, snr_db=snr, freq_offset_hz=foff)
+        d = RefCQPSK(sample_rate=fs, symbol_rate=sr)
+        calls = [7000, 33, 9000, n - 16033]
+        dib, pos = [], 0
+        for m in calls:
+            dib.append(d.demodulate(iq[pos:pos + m]))
+            pos += m
+        out[f"c{ci}_args"] = np.array([fs, sr, n, seed, int(snr * 10), int(foff * 10)], dtype=np.int64)
+        out[f"c{ci}_calls"] = np.array(calls, dtype=np.int64)
+        out[f"c{ci}_sha"] = np.array(S.sha256(iq))
+        out[f"c{ci}_dibits"] = np.concatenate(dib).astype(np.uint8)
+        out[f"c{ci}_counts"] = np.array([len(x) for x in dib], dtype=np.int64)
+        out[f"c{ci}_state"] = np.array([d._carrier_loop._phase, d._carrier_loop._freq, d._timing_recovery._phase,
+                                        d._timing_recovery._integrator])
+    out["n_cases"] = np.array(len(cases))
+    # GardnerTED on a C4FM-like real waveform (10 sps), two blocks
+    rng = np.random.default_rng(1600)
+    sym = rng.choice([-3.0, -1.0, 1.0, 3.0], size=700)
+    x = np.repeat(sym, 10).astype(np.float64)
+    x = np.convolve(x, np.hanning(15) / np.sum(np.hanning(15)), mode="same") + 0.05 * rng.standard_normal(x.size)
+    x = x.astype(np.float32)
+    g = GardnerTED(samples_per_symbol=10.0)
+    s1, e1 = g.process_block(x[:3000])
+    s2, e2 = g.process_block(x[3000:])
+    out["g_sha"] = np.array(S.sha256(x))
+    out["g_sym"] = np.concatenate([s1, s2])
+    out["g_err"] = np.concatenate([e1, e2])
+    out["g_counts"] = np.array([len(s1), len(s2)], dtype=np.int64)
+    g2 = GardnerTED(samples_per_symbol=10.4166666666666661)
+    s3, e3 = g2.process_block(x)
+    out["g2_sym"], out["g2_err"] = s3, e3
+    save("cqpsk", **out)
+
+
+ALL = dict(cqpsk=gen_cqpsk, trunk=gen_trunk, a1=gen_a1, a2=gen_a2, a3=gen_a3, a6=gen_a6, chain=gen_chain, a7=gen_a7, a8=gen_a8, c4fm=gen_c4fm)
 
 if __name__ == "__main__":
     import logging

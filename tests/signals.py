@@ -164,3 +164,31 @@ def c4fm_iq(
         a, b = silence
         iq[a:b] = 0.0
     return (iq + noise).astype(np.complex64), dib
+
+
+# --------------------------------------------------------------------------
+# P25 Phase-2 style pi/4-DQPSK transmitter (for the CQPSK demodulator rows)
+# --------------------------------------------------------------------------
+
+_DQPSK_STEP = np.array([np.pi / 4, 3 * np.pi / 4, -3 * np.pi / 4, -np.pi / 4])  # dibit -> phase change
+
+
+def dqpsk_iq(n: int, fs: float, seed: int, symbol_rate: float = 12000.0, snr_db: float = 25.0,
+             freq_offset_hz: float = 0.0, amp: float = 0.6) -> tuple[np.ndarray, np.ndarray]:
+    """pi/4-DQPSK at complex baseband, RRC(alpha=1) shaped, integer samples per symbol."""
+    sps = int(round(fs / symbol_rate))
+    n_sym = n // sps + 16
+    rng = np.random.default_rng(seed)
+    dib = rng.integers(0, 4, size=n_sym, dtype=np.uint8)
+    ph = np.cumsum(_DQPSK_STEP[dib])
+    up = np.zeros(n_sym * sps, dtype=np.complex128)
+    up[::sps] = np.exp(1j * ph)
+    t = (np.arange(8 * sps + 1) - 4 * sps) / sps
+    h = _rrc_pulse(t.astype(np.float64), 1.0)
+    h /= np.sum(h)
+    x = np.convolve(up, h)[4 * sps: 4 * sps + n] * sps
+    tt = np.arange(n) / fs
+    x = amp * x * np.exp(2j * np.pi * freq_offset_hz * tt)
+    sigma = amp * 10 ** (-snr_db / 20.0) / np.sqrt(2.0)
+    x = x + sigma * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+    return x.astype(np.complex64), dib

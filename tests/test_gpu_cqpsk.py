@@ -1,0 +1,65 @@
+"""GPU parity for row A12: Phase-2 CQPSK chain (dibits exact vs reference goldens and C oracle,
+symbols within 1e-9) and the Gardner TED bank (float64, bit-exact)."""
+
+import numpy as np
+import pytest
+
+import signals as S
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cqpsk_golden_and_oracle(golden):
+    import wavehip
+    from oracle.cqpsk_c import CQPSKDemodulatorRef
+    from test_cqpsk_oracle import cqpsk_case
+
+    g = golden("cqpsk")
+    for ci in range(int(g["n_cases"])):
+        fs, sr, iq, calls = cqpsk_case(g, ci)
+        d = wavehip.CQPSKDemodulator(sample_rate=fs, symbol_rate=sr)
+        dib, pos = [], 0
+        for m in calls:
+            dib.append(d.demodulate(iq[pos:pos + m]))
+            pos += m
+        assert [len(x) for x in dib] == [int(v) for v in g[f"c{ci}_counts"]], ci
+        assert np.array_equal(np.concatenate(dib), g[f"c{ci}_dibits"]), ci
+    # bank of 8 channels vs the C oracle, symbols too
+    fs, sr, n, C = 48000, 12000, 20000, 8
+    xs = np.stack([S.dqpsk_iq(n, fs, 1700 + c, symbol_rate=sr, snr_db=10.0 + 3 * c, freq_offset_hz=30.0 * c - 100)[0]
+                   for c in range(C)])
+    bank = wavehip.CQPSKBank(C, fs, sr, max_samples_per_call=8192)
+    refs = [CQPSKDemodulatorRef(fs, sr) for _ in range(C)]
+    for s in range(0, n, 8192):
+        got = bank.demodulate(xs[:, s:s + 8192], want_symbols=True)
+        for c in range(C):
+            rd, rs = refs[c].demodulate(xs[c, s:s + 8192], want_symbols=True)
+            assert np.array_equal(got[c][0], rd), (c, s)
+            assert np.max(np.abs(got[c][1] - rs)) <= 1e-9 * max(1.0, np.max(np.abs(rs))), (c, s)
+    bank.reset()
+    again = bank.demodulate(xs[:, :4096])
+    fresh = wavehip.CQPSKBank(C, fs, sr, max_samples_per_call=8192).demodulate(xs[:, :4096])
+    assert all(np.array_equal(a, b) for a, b in zip(again, fresh))
+
+
+def test_gardner_bit_exact(golden):
+    import torch
+    import wavehip
+    from test_cqpsk_oracle import gardner_input
+
+    g = golden("cqpsk")
+    x = gardner_input()
+    t = wavehip.GardnerTED(10.0)
+    s1, e1 = t.process_block(x[:3000])
+    s2, e2 = t.process_block(x[3000:])
+    assert s1.dtype == np.float64 and [len(s1), len(s2)] == [int(v) for v in g["g_counts"]]
+    assert np.array_equal(np.concatenate([s1, s2]), g["g_sym"]) and np.array_equal(np.concatenate([e1, e2]), g["g_err"])
+    s3, e3 = wavehip.GardnerTED(10.4166666666666661).process_block(x)
+    assert np.array_equal(s3, g["g2_sym"]) and np.array_equal(e3, g["g2_err"])
+    # a bank: channel c gets x scaled by (c+1) -> symbols scale exactly for powers of two
+    bank = wavehip.GardnerBank(4, 10.0)
+    xb = torch.from_numpy(np.stack([x * s for s in (1.0, 2.0, 4.0, 0.5)])).cuda()
+    sym, err, cnt = bank.process_device(xb)
+    k = int(cnt[0])
+    ref = wavehip.GardnerTED(10.0).process_block(x)
+    assert np.array_equal(sym[0, :k].cpu().numpy(), ref[0])

@@ -1,0 +1,179 @@
+"""P25 Phase-2 CQPSK demodulator and Gardner TED on the MI355X (row A12).
+
+Drop-ins for wavecapsdr.dsp.p25.cqpsk.CQPSKDemodulator (cqpsk.py:199-350: same ctor defaults,
+`demodulate(iq) -> dibits uint8`, `reset()`, `get_carrier_offset()` is not tracked on the host)
+and wavecapsdr.dsp.p25.symbol_timing.GardnerTED (symbol_timing.py:60-211: `process_block(samples)
+-> (symbols float64, errors float64)`, `reset()`), plus batched banks (one lane per channel --
+both algorithms are per-sample feedback loops).  Float64 throughout, like the reference."""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+from scipy import signal
+
+from . import _lib
+
+
+def calculate_loop_coefficients(samples_per_symbol: float, loop_bw: float = 0.01, damping: float = 1.0):
+    """symbol_timing.py:34-57 (samples_per_symbol is unused by the reference formula as well)."""
+    theta = loop_bw / (damping + 1 / (4 * damping))
+    d = 1 + 2 * damping * theta + theta ** 2
+    return 4 * damping * theta / d, 4 * theta ** 2 / d
+
+
+def design_rrc_filter_phase2(samples_per_symbol: float, num_taps: int = 65, alpha: float = 1.0) -> np.ndarray:
+    """cqpsk.py:35-81."""
+    if num_taps % 2 == 0:
+        num_taps += 1
+    t = (np.arange(num_taps) - (num_taps - 1) / 2) / samples_per_symbol
+    h = np.zeros(num_taps, dtype=np.float64)
+    for i, ti in enumerate(t):
+        if ti == 0:
+            h[i] = 1 - alpha + 4 * alpha / np.pi
+        elif abs(ti * 4 * alpha) == 1:
+            h[i] = (alpha / np.sqrt(2)) * ((1 + 2 / np.pi) * np.sin(np.pi / (4 * alpha))
+                                           + (1 - 2 / np.pi) * np.cos(np.pi / (4 * alpha)))
+        else:
+            num = np.sin(np.pi * ti * (1 - alpha)) + 4 * alpha * ti * np.cos(np.pi * ti * (1 + alpha))
+            den = np.pi * ti * (1 - (4 * alpha * ti) ** 2)
+            h[i] = num / den if abs(den) > 1e-10 else 0
+    return np.asarray(h / np.sqrt(np.sum(h ** 2)), dtype=np.float32)
+
+
+class CQPSKBank:
+    def __init__(self, n_channels: int, sample_rate: int = 48000, symbol_rate: int = 12000, rrc_alpha: float = 1.0,
+                 rrc_taps: int = 65, carrier_loop_bw: float = 0.01, timing_loop_bw: float = 0.01,
+                 max_samples_per_call: int = 1 << 16):
+        self._torch = _lib.require_gpu()
+        self.n_channels = int(n_channels)
+        self.sample_rate, self.symbol_rate = sample_rate, symbol_rate
+        self.samples_per_symbol = sample_rate / symbol_rate
+        self.max_samples_per_call = int(max_samples_per_call)
+        self._rrc = design_rrc_filter_phase2(self.samples_per_symbol, rrc_taps, rrc_alpha)
+        zi = np.ascontiguousarray(signal.lfilter_zi(self._rrc, 1.0), dtype=np.float64)
+        ckp, cki = calculate_loop_coefficients(0.0, carrier_loop_bw, 0.707)      # cqpsk.py:107-110
+        tkp, tki = calculate_loop_coefficients(self.samples_per_symbol, timing_loop_bw, 1.0)
+        self._h = C.c_void_p()
+        self._destroy = _lib.lib.wh_cqpsk_bank_destroy
+        _lib.check(_lib.lib.wh_cqpsk_bank_create(C.byref(self._h), self.n_channels, float(self.samples_per_symbol),
+                                                 _lib.dptr(self._rrc, "f32"), len(self._rrc), _lib.dptr(zi, "f64"),
+                                                 ckp, cki, 0.1, tkp, tki, self.max_samples_per_call),
+                   "wh_cqpsk_bank_create")
+        torch = self._torch
+        self.cap = int(self.max_samples_per_call / (self.samples_per_symbol * 0.5)) + 8
+        self._dibits = torch.empty((self.n_channels, self.cap), dtype=torch.uint8, device="cuda")
+        self._symbols = torch.empty((self.n_channels, self.cap), dtype=torch.complex128, device="cuda")
+        self._counts = torch.zeros(self.n_channels, dtype=torch.int32, device="cuda")
+
+    def __del__(self):
+        h, destroy = getattr(self, "_h", None), getattr(self, "_destroy", None)
+        if h and destroy:
+            destroy(h)
+            self._h = None
+
+    def reset(self) -> None:
+        _lib.check(_lib.lib.wh_cqpsk_bank_reset(self._h, _lib.stream_ptr(self._torch)), "wh_cqpsk_bank_reset")
+
+    def demodulate_device(self, iq_dev, want_symbols: bool = False):
+        torch = self._torch
+        assert iq_dev.is_cuda and iq_dev.dtype == torch.complex64 and iq_dev.dim() == 2
+        assert iq_dev.shape[0] == self.n_channels and iq_dev.stride(1) == 1
+        n = iq_dev.shape[1]
+        stride = iq_dev.stride(0) if self.n_channels > 1 else n
+        _lib.check(_lib.lib.wh_cqpsk_bank_run(self._h, iq_dev.data_ptr(), n, stride, self._dibits.data_ptr(),
+                                              self._symbols.data_ptr() if want_symbols else None, self.cap,
+                                              self._counts.data_ptr(), _lib.stream_ptr(torch)), "wh_cqpsk_bank_run")
+        return self._dibits, self._symbols, self._counts
+
+    def demodulate(self, iq, want_symbols: bool = False):
+        torch = self._torch
+        x = np.ascontiguousarray(iq, dtype=np.complex64)
+        assert x.ndim == 2 and x.shape[0] == self.n_channels
+        outs = [([], []) for _ in range(self.n_channels)]
+        for s in range(0, x.shape[1], self.max_samples_per_call):
+            part = np.ascontiguousarray(x[:, s:s + self.max_samples_per_call])
+            d, sy, cnt = self.demodulate_device(torch.from_numpy(part).cuda(), want_symbols)
+            d, cnt = d.cpu().numpy(), cnt.cpu().numpy()
+            sy = sy.cpu().numpy() if want_symbols else None
+            for c in range(self.n_channels):
+                outs[c][0].append(d[c, :cnt[c]].copy())
+                if want_symbols:
+                    outs[c][1].append(sy[c, :cnt[c]].copy())
+        if want_symbols:
+            return [(np.concatenate(a), np.concatenate(b)) for a, b in outs]
+        return [np.concatenate(a) if a else np.array([], np.uint8) for a, _ in outs]
+
+
+class CQPSKDemodulator:
+    """Single-channel drop-in (cqpsk.py:224-306)."""
+
+    def __init__(self, sample_rate: int = 48000, symbol_rate: int = 12000, rrc_alpha: float = 1.0,
+                 rrc_taps: int = 65, carrier_loop_bw: float = 0.01, timing_loop_bw: float = 0.01):
+        self.sample_rate, self.symbol_rate = sample_rate, symbol_rate
+        self.samples_per_symbol = sample_rate / symbol_rate
+        self._bank = CQPSKBank(1, sample_rate, symbol_rate, rrc_alpha, rrc_taps, carrier_loop_bw, timing_loop_bw)
+
+    def reset(self) -> None:
+        self._bank.reset()
+
+    def demodulate(self, iq):
+        if len(iq) == 0:
+            return np.array([], dtype=np.uint8)
+        return self._bank.demodulate(np.asarray(iq)[None, :])[0]
+
+
+class GardnerBank:
+    def __init__(self, n_channels: int, samples_per_symbol: float, loop_bw: float = 0.01, damping: float = 1.0):
+        self._torch = _lib.require_gpu()
+        self.n_channels = int(n_channels)
+        self.samples_per_symbol = float(samples_per_symbol)
+        kp, ki = calculate_loop_coefficients(samples_per_symbol, loop_bw, damping)
+        self._h = C.c_void_p()
+        self._destroy = _lib.lib.wh_gardner_bank_destroy
+        _lib.check(_lib.lib.wh_gardner_bank_create(C.byref(self._h), self.n_channels, self.samples_per_symbol, kp, ki),
+                   "wh_gardner_bank_create")
+
+    def __del__(self):
+        h, destroy = getattr(self, "_h", None), getattr(self, "_destroy", None)
+        if h and destroy:
+            destroy(h)
+            self._h = None
+
+    def reset(self) -> None:
+        _lib.check(_lib.lib.wh_gardner_bank_reset(self._h, _lib.stream_ptr(self._torch)), "wh_gardner_bank_reset")
+
+    def process_device(self, x_dev):
+        """x_dev: float32 GPU tensor [C, n] -> (symbols f64 [C, cap], errors f64 [C, cap], counts int32 [C])."""
+        torch = self._torch
+        assert x_dev.is_cuda and x_dev.dtype == torch.float32 and x_dev.dim() == 2 and x_dev.stride(1) == 1
+        n = x_dev.shape[1]
+        cap = int(n / (self.samples_per_symbol * 0.5)) + 8
+        sym = torch.empty((self.n_channels, cap), dtype=torch.float64, device="cuda")
+        err = torch.empty((self.n_channels, cap), dtype=torch.float64, device="cuda")
+        cnt = torch.zeros(self.n_channels, dtype=torch.int32, device="cuda")
+        stride = x_dev.stride(0) if self.n_channels > 1 else n
+        _lib.check(_lib.lib.wh_gardner_bank_run(self._h, x_dev.data_ptr(), n, stride, sym.data_ptr(), err.data_ptr(),
+                                                cap, cnt.data_ptr(), _lib.stream_ptr(torch)), "wh_gardner_bank_run")
+        return sym, err, cnt
+
+
+class GardnerTED:
+    """Single-channel drop-in (symbol_timing.py:60-211)."""
+
+    def __init__(self, samples_per_symbol: float, loop_bw: float = 0.01, damping: float = 1.0):
+        self.samples_per_symbol = samples_per_symbol
+        self._bank = GardnerBank(1, samples_per_symbol, loop_bw, damping)
+
+    def reset(self) -> None:
+        self._bank.reset()
+
+    def process_block(self, samples):
+        x = np.ascontiguousarray(samples, dtype=np.float32)
+        if x.size == 0:
+            return np.array([], dtype=np.float64), np.array([], dtype=np.float64)
+        torch = self._bank._torch
+        s, e, c = self._bank.process_device(torch.from_numpy(x[None, :]).cuda())
+        k = int(c[0])
+        return s[0, :k].cpu().numpy(), e[0, :k].cpu().numpy()
