@@ -192,13 +192,12 @@ def main() -> None:
         ch.channel_stats_device(out[hops - scan:], stats)
         return reduce_channel_stats(stats) if world > 1 else stats
 
-    # untimed pre-warm (~0.3 s of back-to-back steps) so the W warmup + K timed steps run at the
-    # clocks the chip holds under sustained load rather than on the DVFS ramp of a cold device
-    t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < 0.3:
-        for _ in range(8):
-            step()
-        torch.cuda.synchronize()
+    # untimed pre-warm (a FIXED 200 steps ~ 0.3 s, identical on every rank so the collectives stay
+    # matched) so the W warmup + K timed steps run at the clocks the chip holds under sustained
+    # load rather than on the DVFS ramp of a cold device
+    for _ in range(200):
+        step()
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     kernel_ms = []
