@@ -119,6 +119,9 @@ typedef struct wh_pfb wh_pfb;
 int wh_pfb_create(wh_pfb **out, int channel_count, int taps_per_channel, const double *h_arms);
 size_t wh_pfb_hops(const wh_pfb *p, size_t n_samples);
 int wh_pfb_run(wh_pfb *p, const float *d_iq, size_t n_samples, float *d_out, void *stream);
+/* same with interleaved int16 IQ input (A1 unpack rule int16/32768 fused into the loads: 4 B read
+ * per sample instead of 8) */
+int wh_pfb_run_i16(wh_pfb *p, const int16_t *d_iq16, size_t n_samples, float *d_out, void *stream);
 int wh_pfb_reset(wh_pfb *p, void *stream);                       /* channelizer.py:139-142 */
 int wh_pfb_get_history(wh_pfb *p, float *h_hist /* c64[M][T] */, void *stream);
 int wh_pfb_set_history(wh_pfb *p, const float *h_hist, void *stream);

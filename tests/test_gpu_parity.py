@@ -276,6 +276,22 @@ def test_a7_pfb_properties_large(wh):
     assert p[k].item() > 0.75 * p.sum().item()   # the reference's structure leaks into k+-1 (no per-hop shift)
 
 
+def test_a7_pfb_int16_input(wh):
+    """int16 IQ input (unpack fused into the loads) == unpack first, bit for bit; both paths + history."""
+    import torch
+
+    x = S.noise_c64(1024 * 200 + 333, 12, amp=0.25)
+    i16 = S.pack_iq16_np(x)
+    xq = wh.unpack_iq16(i16)
+    for fs, bw in ((10_000_000, 9765), (1_000_000, 25000)):
+        a, b = wh.PolyphaseChannelizer(fs, bw), wh.PolyphaseChannelizer(fs, bw)
+        for lo, hi in ((0, 150000), (150000, len(xq))):
+            ya = a.process_device(torch.from_numpy(i16[2 * lo:2 * hi].copy()).cuda())
+            yb = b.process_device(torch.from_numpy(xq[lo:hi].copy()).cuda())
+            assert torch.equal(ya, yb)
+        assert np.array_equal(a.arm_history, b.arm_history)
+
+
 def test_a8_spectrum(wh, golden):
     g = golden("a8_spectrum")
     for ci in range(int(g["n_cases"])):

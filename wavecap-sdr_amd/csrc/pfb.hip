@@ -34,8 +34,21 @@ constexpr int LDS1_K1 = 272;   // stage-1 image: idx = k1*272 + n2*16 + n3   (co
 constexpr int LDS2_ROW = 18;   // stage-2 image: idx = (k2*4 + k1)*18 + n3
 constexpr int LDS_HOP = 1152;  // complex per hop image (max(4*272, 64*18))
 
+// input accessor: complex64 (FMT 0) or interleaved int16 IQ (FMT 1, A1 unpack rule int16/32768)
+template <int FMT>
+__device__ __forceinline__ float2 ld_iq(const void *p, long long i) {
+    if (FMT == 1) {
+        short2 v = reinterpret_cast<const short2 *>(p)[i];
+        return make_float2((float)v.x * (1.0f / 32768.0f), (float)v.y * (1.0f / 32768.0f));
+    }
+    return reinterpret_cast<const float2 *>(p)[i];
+}
+__device__ __forceinline__ float2 ld_iq_rt(const void *p, int fmt, long long i) {
+    return fmt == 1 ? ld_iq<1>(p, i) : ld_iq<0>(p, i);
+}
+
 struct PfbFastArgs {
-    const float2 *x;        // input samples
+    const void *x;          // input samples (complex64 or int16 pairs)
     float2 *out;            // [hops][1024]
     const float *arms;      // float32 [1024][9]
     const float2 *tw1024;   // exp(-2 pi i m/1024)
@@ -46,6 +59,7 @@ struct PfbFastArgs {
     int ablate;             // diagnostics only (WH_PFB_ABLATE): 1 = suppress stores, 2 = skip LDS+FFT
 };
 
+template <int FMT>
 __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
     __shared__ __attribute__((aligned(16))) float2 lds[GH * LDS_HOP + 256];
     float2 *tw256 = lds + GH * LDS_HOP;
@@ -86,11 +100,11 @@ __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
     // window slots 0..8 carry c_{h-8..h}; slots 9..12 double as the prefetch buffer of the
     // group's new samples (loaded one group ahead, in flight across the FFT phase)
     float2 wA[9 + GH], wB[9 + GH];
-    const float2 *xp = a.x + (h - 8) * FHOP + t;
+    const long long xp = (h - 8) * FHOP + t;
 #pragma unroll
     for (int i = 0; i < 9 + GH; ++i) {
-        wA[i] = xp[i * FHOP];
-        wB[i] = xp[i * FHOP + 256];
+        wA[i] = ld_iq<FMT>(a.x, xp + i * FHOP);
+        wB[i] = ld_iq<FMT>(a.x, xp + i * FHOP + 256);
     }
 
     for (long long g = g0; g < g1; ++g, h += GH) {
@@ -129,11 +143,11 @@ __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
             wB[i] = wB[i + GH];
         }
         if (g + 1 < g1) {
-            const float2 *xn = a.x + (h + GH + 1) * FHOP + t;
+            const long long xn = (h + GH + 1) * FHOP + t;
 #pragma unroll
             for (int i = 0; i < GH; ++i) {
-                wA[9 + i] = xn[i * FHOP];
-                wB[9 + i] = xn[i * FHOP + 256];
+                wA[9 + i] = ld_iq<FMT>(a.x, xn + i * FHOP);
+                wB[9 + i] = ld_iq<FMT>(a.x, xn + i * FHOP + 256);
             }
         }
         __syncthreads();
@@ -188,7 +202,8 @@ __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
 // generic path: one workgroup per hop
 // ------------------------------------------------------------------------------------------
 struct PfbGenArgs {
-    const float2 *x;
+    const void *x;
+    int fmt;
     const float2 *hist;  // [M][T] carried history (column j = block_{-1-j})
     float2 *out;
     const float *arms;   // float32 [M][T]
@@ -199,7 +214,7 @@ struct PfbGenArgs {
 };
 
 __device__ __forceinline__ float2 gen_block(const PfbGenArgs &a, long long g, int k) {
-    if (g >= 0) return a.x[g * (a.M / 2) + k];
+    if (g >= 0) return ld_iq_rt(a.x, a.fmt, g * (a.M / 2) + k);
     int col = (int)(-g - 1);
     if (col >= a.T) return make_float2(0.f, 0.f);
     return a.hist[(size_t)k * a.T + col];
@@ -261,14 +276,14 @@ __global__ __launch_bounds__(256) void pfb_generic_kernel(PfbGenArgs a) {
 }
 
 // new_hist[k][j] = block_{H-1-j}[k]
-__global__ void pfb_hist_kernel(const float2 *x, const float2 *old_hist, float2 *new_hist, int M, int T,
+__global__ void pfb_hist_kernel(const void *x, int fmt, const float2 *old_hist, float2 *new_hist, int M, int T,
                                 long long H) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= M * T) return;
     int k = idx / T, j = idx % T;
     long long g = H - 1 - j;
     float2 v;
-    if (g >= 0) v = x[g * (M / 2) + k];
+    if (g >= 0) v = ld_iq_rt(x, fmt, g * (M / 2) + k);
     else {
         int col = (int)(-g - 1);
         v = col < T ? old_hist[(size_t)k * T + col] : make_float2(0.f, 0.f);
@@ -424,11 +439,12 @@ extern "C" size_t wh_pfb_hops(const wh_pfb *p, size_t n) {
     return (n - p->M) / (p->M / 2) + 1;
 }
 
-static int launch_generic(wh_pfb *p, const float *d_iq, float *d_out, long long hop0, long long n_hops,
+static int launch_generic(wh_pfb *p, const void *d_iq, int fmt, float *d_out, long long hop0, long long n_hops,
                           hipStream_t st) {
     if (n_hops <= 0) return WH_OK;
     PfbGenArgs a;
-    a.x = reinterpret_cast<const float2 *>(d_iq);
+    a.x = d_iq;
+    a.fmt = fmt;
     a.hist = p->d_hist[p->cur];
     a.out = reinterpret_cast<float2 *>(d_out);
     a.arms = p->d_arms;
@@ -452,7 +468,17 @@ static int launch_generic(wh_pfb *p, const float *d_iq, float *d_out, long long 
     return WH_OK;
 }
 
+static int pfb_run_fmt(wh_pfb *p, const void *d_iq, int fmt, size_t n, float *d_out, void *stream);
+
 extern "C" int wh_pfb_run(wh_pfb *p, const float *d_iq, size_t n, float *d_out, void *stream) {
+    return pfb_run_fmt(p, d_iq, 0, n, d_out, stream);
+}
+
+extern "C" int wh_pfb_run_i16(wh_pfb *p, const int16_t *d_iq16, size_t n, float *d_out, void *stream) {
+    return pfb_run_fmt(p, d_iq16, 1, n, d_out, stream);
+}
+
+static int pfb_run_fmt(wh_pfb *p, const void *d_iq, int fmt, size_t n, float *d_out, void *stream) {
     if (!p) return set_err(WH_E_ARG, "wh_pfb_run: null handle");
     hipStream_t st = as_stream(stream);
     long long H = (long long)wh_pfb_hops(p, n);
@@ -461,12 +487,12 @@ extern "C" int wh_pfb_run(wh_pfb *p, const float *d_iq, size_t n, float *d_out, 
     int rc;
     const bool fast = (p->M == FM && p->T == FT);
     long long head = fast ? (H < 8 ? H : 8) : H;
-    if ((rc = launch_generic(p, d_iq, d_out, 0, head, st)) != WH_OK) return rc;
+    if ((rc = launch_generic(p, d_iq, fmt, d_out, 0, head, st)) != WH_OK) return rc;
     if (fast && H > 8) {
         long long n_groups = (H - 8) / GH;
         if (n_groups > 0) {
             PfbFastArgs a;
-            a.x = reinterpret_cast<const float2 *>(d_iq);
+            a.x = d_iq;
             a.out = reinterpret_cast<float2 *>(d_out);
             a.arms = p->d_arms;
             a.tw1024 = p->d_tw;
@@ -487,7 +513,10 @@ extern "C" int wh_pfb_run(wh_pfb *p, const float *d_iq, size_t n, float *d_out, 
             a.n_wg = (int)nwg;
             a.ablate = p->ablate;
             if (p->prof) WH_HIP(hipEventRecord(p->ev0, st));
-            hipLaunchKernelGGL(pfb1024_kernel, dim3((unsigned)nwg), dim3(256), 0, st, a);
+            if (fmt == 1)
+                hipLaunchKernelGGL(pfb1024_kernel<1>, dim3((unsigned)nwg), dim3(256), 0, st, a);
+            else
+                hipLaunchKernelGGL(pfb1024_kernel<0>, dim3((unsigned)nwg), dim3(256), 0, st, a);
             WH_LAUNCH_CHECK();
             if (p->prof) {
                 WH_HIP(hipEventRecord(p->ev1, st));
@@ -495,13 +524,13 @@ extern "C" int wh_pfb_run(wh_pfb *p, const float *d_iq, size_t n, float *d_out, 
             }
         }
         long long done = 8 + n_groups * GH;
-        if ((rc = launch_generic(p, d_iq, d_out, done, H - done, st)) != WH_OK) return rc;
+        if ((rc = launch_generic(p, d_iq, fmt, d_out, done, H - done, st)) != WH_OK) return rc;
     }
     // carry the history
     int nxt = p->cur ^ 1;
     int tot = p->M * p->T;
-    hipLaunchKernelGGL(pfb_hist_kernel, dim3((tot + 255) / 256), dim3(256), 0, st,
-                       reinterpret_cast<const float2 *>(d_iq), p->d_hist[p->cur], p->d_hist[nxt], p->M, p->T, H);
+    hipLaunchKernelGGL(pfb_hist_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, d_iq, fmt, p->d_hist[p->cur],
+                       p->d_hist[nxt], p->M, p->T, H);
     WH_LAUNCH_CHECK();
     p->cur = nxt;
     return WH_OK;

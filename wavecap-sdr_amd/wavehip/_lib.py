@@ -83,6 +83,7 @@ PROTOTYPES = {
     "wh_pfb_create": (c_int, [C.POINTER(c_void_p), c_int, c_int, C.POINTER(c_double)]),
     "wh_pfb_hops": (c_size_t, [c_void_p, c_size_t]),
     "wh_pfb_run": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "wh_pfb_run_i16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "wh_pfb_reset": (c_int, [c_void_p, c_void_p]),
     "wh_pfb_get_history": (c_int, [c_void_p, c_void_p, c_void_p]),
     "wh_pfb_set_history": (c_int, [c_void_p, c_void_p, c_void_p]),

@@ -81,18 +81,22 @@ class PolyphaseChannelizer:
         return int(_lib.lib.wh_pfb_hops(self._h, n_samples))
 
     def process_device(self, samples, out=None):
-        """samples: complex64 torch tensor on the GPU -> complex64 tensor [hops, M] on the GPU."""
+        """samples: complex64 (or interleaved int16 IQ) torch tensor on the GPU -> complex64 tensor
+        [hops, M] on the GPU."""
         torch = self._torch
-        assert samples.is_cuda and samples.dtype == torch.complex64 and samples.is_contiguous()
-        n = samples.numel()
+        assert samples.is_cuda and samples.is_contiguous()
+        if samples.dtype == torch.int16:          # interleaved int16 IQ: unpack fused into the loads
+            n, run = samples.numel() // 2, _lib.lib.wh_pfb_run_i16
+        else:
+            assert samples.dtype == torch.complex64
+            n, run = samples.numel(), _lib.lib.wh_pfb_run
         H = self.hops(n)
         if out is None:
             out = torch.empty((H, self.channel_count), dtype=torch.complex64, device=samples.device)
         else:
             assert out.is_cuda and out.dtype == torch.complex64 and out.is_contiguous()
             assert out.numel() >= H * self.channel_count
-        _lib.check(_lib.lib.wh_pfb_run(self._h, samples.data_ptr(), n, out.data_ptr(), _lib.stream_ptr(torch)),
-                   "wh_pfb_run")
+        _lib.check(run(self._h, samples.data_ptr(), n, out.data_ptr(), _lib.stream_ptr(torch)), "wh_pfb_run")
         return out
 
     def process(self, samples) -> np.ndarray:
