@@ -68,3 +68,40 @@ def test_reduce_is_identity_without_process_group():
 
     s = torch.rand(8, 5, dtype=torch.float64)
     assert reduce_channel_stats(s) is s
+
+
+def _worker_async(rank: int, world: int, port: int, out_dir: str):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "wavecap-sdr_amd")]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from wavehip.scanner_reduce import AsyncStatsReducer
+
+    red = AsyncStatsReducer()
+    outs = []
+    for i in range(3):
+        s = torch.full((16, 5), float(rank + 1 + 10 * i), dtype=torch.float64)
+        prev = red.wait()
+        red.submit(s)
+        if prev is not None:
+            outs.append(prev)
+    outs.append(red.wait())
+    torch.save(outs, os.path.join(out_dir, f"a{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_async_stats_reducer_world2(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker_async, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        outs = torch.load(os.path.join(str(tmp_path), f"a{r}.pt"), weights_only=True)
+        assert len(outs) == 3
+        for i, m in enumerate(outs):
+            a, b = 1.0 + 10 * i, 2.0 + 10 * i
+            assert torch.equal(m[:, 0:3], torch.full((16, 3), a + b, dtype=torch.float64))
+            assert torch.equal(m[:, 3], torch.full((16,), a, dtype=torch.float64))
+            assert torch.equal(m[:, 4], torch.full((16,), b, dtype=torch.float64))

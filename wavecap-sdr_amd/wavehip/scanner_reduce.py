@@ -26,6 +26,39 @@ def reduce_channel_stats(stats, group=None):
     return torch.cat([sums, mn[:, None], mx[:, None]], dim=1)
 
 
+class AsyncStatsReducer:
+    """One collective per scan instead of three, overlapped with the next compute step:
+    `submit(stats)` all-gathers the packed [M, 5] block asynchronously (RCCL runs it on its own
+    stream after the producing kernel), `result()` waits and merges sum / min / max locally.
+    Double-buffered so a scan can be in flight while the next one is produced."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self._pending = None      # (work, gathered tensor)
+
+    def submit(self, stats):
+        import torch
+        import torch.distributed as dist
+
+        self.wait()
+        world = dist.get_world_size(self.group)
+        out = torch.empty((world * stats.shape[0],) + tuple(stats.shape[1:]), dtype=stats.dtype, device=stats.device)
+        work = dist.all_gather_into_tensor(out, stats.contiguous(), group=self.group, async_op=True)
+        self._pending = (work, out.view((world,) + tuple(stats.shape)))
+
+    def wait(self):
+        """Block the CURRENT stream on the pending collective (no host sync) and return the merge."""
+        import torch
+
+        if self._pending is None:
+            return None
+        work, out = self._pending
+        self._pending = None
+        work.wait()
+        return torch.cat([out[:, :, 0:3].sum(0), out[:, :, 3].min(0).values[:, None],
+                          out[:, :, 4].max(0).values[:, None]], dim=1)
+
+
 def gather_measurements(meas, group=None):
     """meas: float64 tensor [n, F] of per-stream candidate measurements
     (power_db, snr_db, sync flag ...).  Returns [world, n, F] on every rank."""
