@@ -19,6 +19,7 @@
 // tail hops of the fast path.
 #include "wh_common.h"
 #include <cmath>
+#include <cstdint>
 #include <cstdlib>
 #include <vector>
 
@@ -56,7 +57,7 @@ struct PfbFastArgs {
     long long n_groups;     // total groups of GH hops
     int groups_per_wg;
     int n_wg;
-    int ablate;             // diagnostics only (WH_PFB_ABLATE): 1 = suppress stores, 2 = skip LDS+FFT
+    int ablate;             // diagnostics only (WH_PFB_ABLATE): 1 = suppress stores
 };
 
 template <int FMT>
@@ -89,9 +90,10 @@ __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
 
     // stage-1 twiddles W1024^(t*k1), k1 = 1..3
     float2 tw1 = a.tw1024[t], tw2 = a.tw1024[(2 * t) & 1023], tw3 = a.tw1024[(3 * t) & 1023];
-    // stage-2 twiddles W256^(n3*k2) are read from a 2 KB LDS table (keeping the 15 per-lane values
-    // in registers instead pushes the kernel to 256 VGPRs and measured 18 % slower)
-    tw256[t] = a.tw1024[4 * t];
+    // stage-2 twiddles W256^(n3*k2) are read from a 2 KB LDS table laid out [k2][n3], so a wave's
+    // read for one k2 is 16 consecutive entries (conflict-free, broadcast over k1, immediate offsets).
+    // (Keeping the 15 per-lane values in registers pushes the kernel to 256 VGPRs: 18 % slower.)
+    tw256[t] = a.tw1024[(4 * (t & 15) * (t >> 4)) & 1023];
     __syncthreads();
 
     long long h = a.first_hop + g0 * GH;  // first hop of this run
@@ -156,9 +158,11 @@ __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
             float2 *L = lds + wave * LDS_HOP;
             const int k1 = lane >> 4, n3 = lane & 15;
             float2 v[16];
-            const float2 *src = L + k1 * LDS1_K1 + n3;
+            {   // (forcing 16 ds_read_b64 through inline asm instead of hipcc's 8 ds_read2_b64 measured no gain)
+                const float2 *src = L + k1 * LDS1_K1 + n3;
 #pragma unroll
-            for (int n2 = 0; n2 < 16; ++n2) v[n2] = src[n2 * 16];
+                for (int n2 = 0; n2 < 16; ++n2) v[n2] = src[n2 * 16];
+            }
             fft16(v);
             // twiddle W256^(n3*k2) and store to image 2 (same wave only: no barrier needed,
             // every lane's reads above were issued before these writes)
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
             dst[0] = v[0];
 #pragma unroll
             for (int k2 = 1; k2 < 16; ++k2) {
-                float2 w = tw256[(n3 * k2) & 255];
+                float2 w = tw256[k2 * 16 + n3];
                 dst[k2 * 4 * LDS2_ROW] = cmul(v[k2], w);
             }
         }
@@ -176,22 +180,52 @@ __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
         {
             float2 *L = lds + wave * LDS_HOP;
             float2 v[16];
-            const float4 *src = reinterpret_cast<const float4 *>(L + lane * LDS2_ROW);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                float4 p = src[q];
-                v[2 * q] = make_float2(p.x, p.y);
-                v[2 * q + 1] = make_float2(p.z, p.w);
+            // 8 x ds_read_b128 by inline asm: written as float4 loads, hipcc scalarises them into
+            // 16 ds_read2_b32 (real/imag de-interleaved), which at the 144-byte row stride is a 4-way
+            // bank conflict (measured: SQ_LDS_BANK_CONFLICT > SQ_ACTIVE_INST_LDS).  b128 reads of the
+            // padded rows are conflict-free.  The asm loads are waited for explicitly (lgkmcnt).
+            {
+                typedef float f4 __attribute__((ext_vector_type(4)));
+                const unsigned addr = static_cast<unsigned>(reinterpret_cast<uintptr_t>(L + lane * LDS2_ROW));
+                f4 r0, r1, r2, r3, r4, r5, r6, r7;
+                asm volatile("ds_read_b128 %0, %8\n\t"
+                             "ds_read_b128 %1, %8 offset:16\n\t"
+                             "ds_read_b128 %2, %8 offset:32\n\t"
+                             "ds_read_b128 %3, %8 offset:48\n\t"
+                             "ds_read_b128 %4, %8 offset:64\n\t"
+                             "ds_read_b128 %5, %8 offset:80\n\t"
+                             "ds_read_b128 %6, %8 offset:96\n\t"
+                             "ds_read_b128 %7, %8 offset:112\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+                             : "v"(addr)
+                             : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                v[0] = make_float2(r0.x, r0.y);   v[1] = make_float2(r0.z, r0.w);
+                v[2] = make_float2(r1.x, r1.y);   v[3] = make_float2(r1.z, r1.w);
+                v[4] = make_float2(r2.x, r2.y);   v[5] = make_float2(r2.z, r2.w);
+                v[6] = make_float2(r3.x, r3.y);   v[7] = make_float2(r3.z, r3.w);
+                v[8] = make_float2(r4.x, r4.y);   v[9] = make_float2(r4.z, r4.w);
+                v[10] = make_float2(r5.x, r5.y);  v[11] = make_float2(r5.z, r5.w);
+                v[12] = make_float2(r6.x, r6.y);  v[13] = make_float2(r6.z, r6.w);
+                v[14] = make_float2(r7.x, r7.y);  v[15] = make_float2(r7.z, r7.w);
             }
             fft16(v);
-            float2 *o = a.out + (h + wave) * FM + lane;  // k = lane + 64*k3
-            if (a.ablate == 3) {
+            {
+                // 16-byte stores (+2.3 % over 8-byte ones): lanes 2m / 2m+1 swap half of their outputs so that
+                // the even lane owns (X[2m + 64 j], X[2m+1 + 64 j]) for j < 8 and the odd lane the pair for j >= 8
+                const bool even = (lane & 1) == 0;
+                float4 *o4 = reinterpret_cast<float4 *>(a.out + (h + wave) * FM + (lane & ~1) + (even ? 0 : 512));
 #pragma unroll
-                for (int k3 = 0; k3 < 16; ++k3)
-                    __builtin_nontemporal_store(*reinterpret_cast<double *>(&v[k3]), reinterpret_cast<double *>(o + 64 * k3));
-            } else if (a.ablate != 1 || v[0].x == 1.2345e30f) {
-#pragma unroll
-                for (int k3 = 0; k3 < 16; ++k3) o[64 * k3] = v[k3];
+                for (int j = 0; j < 8; ++j) {
+                    float2 snd = even ? v[j + 8] : v[j];
+                    float2 rcv;
+                    rcv.x = __shfl_xor(snd.x, 1);
+                    rcv.y = __shfl_xor(snd.y, 1);
+                    float2 lo = even ? v[j] : rcv;
+                    float2 hi = even ? rcv : v[j + 8];
+                    if (a.ablate != 1 || lo.x == 1.2345e30f) o4[32 * j] = make_float4(lo.x, lo.y, hi.x, hi.y);
+                }
             }
         }
         __syncthreads();
