@@ -243,8 +243,10 @@ struct PfbGenArgs {
     const float *arms;   // float32 [M][T]
     const float2 *tw;    // exp(-2 pi i m / M), m in [0, M)
     int M, T, log2M;     // log2M = 0 when M is not a power of two
-    long long hop0;      // first hop handled
-    long long n_hops;    // hops handled (grid.x)
+    long long hop0;      // first hop of range A (blocks [0, n_hops))
+    long long n_hops;
+    long long hop0b;     // first hop of range B (blocks [n_hops, n_hops + n_hops_b)); lets the head
+    long long n_hops_b;  // (carried history) and the ragged tail of the fast path share one launch
 };
 
 __device__ __forceinline__ float2 gen_block(const PfbGenArgs &a, long long g, int k) {
@@ -256,7 +258,8 @@ __device__ __forceinline__ float2 gen_block(const PfbGenArgs &a, long long g, in
 
 __global__ __launch_bounds__(256) void pfb_generic_kernel(PfbGenArgs a) {
     extern __shared__ __attribute__((aligned(16))) float2 sm[];  // M complex (+M for pow2 ping-pong)
-    const long long h = a.hop0 + blockIdx.x;
+    const long long h = (long long)blockIdx.x < a.n_hops ? a.hop0 + blockIdx.x
+                                                          : a.hop0b + ((long long)blockIdx.x - a.n_hops);
     const int M = a.M, T = a.T;
     for (int k = threadIdx.x; k < M; k += blockDim.x) {
         float re = 0.f, im = 0.f;
@@ -474,8 +477,10 @@ extern "C" size_t wh_pfb_hops(const wh_pfb *p, size_t n) {
 }
 
 static int launch_generic(wh_pfb *p, const void *d_iq, int fmt, float *d_out, long long hop0, long long n_hops,
-                          hipStream_t st) {
-    if (n_hops <= 0) return WH_OK;
+                          hipStream_t st, long long hop0b = 0, long long n_hops_b = 0) {
+    if (n_hops_b < 0) n_hops_b = 0;
+    if (n_hops <= 0 && n_hops_b <= 0) return WH_OK;
+    if (n_hops < 0) n_hops = 0;
     PfbGenArgs a;
     a.x = d_iq;
     a.fmt = fmt;
@@ -485,6 +490,7 @@ static int launch_generic(wh_pfb *p, const void *d_iq, int fmt, float *d_out, lo
     a.tw = p->d_tw;
     a.M = p->M; a.T = p->T; a.log2M = p->log2M;
     a.hop0 = hop0; a.n_hops = n_hops;
+    a.hop0b = hop0b; a.n_hops_b = n_hops_b;
     size_t smem = (size_t)p->M * sizeof(float2) * (p->log2M ? 2 : 1);
     if (smem > 64 * 1024) {
         WH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pfb_generic_kernel),
@@ -492,6 +498,11 @@ static int launch_generic(wh_pfb *p, const void *d_iq, int fmt, float *d_out, lo
     }
     // grid.x is limited to 2^31-1; chunk very long tails (never happens for the fast path)
     const long long MAXG = 1 << 30;
+    if (n_hops_b > 0) {   // two short ranges in one launch
+        hipLaunchKernelGGL(pfb_generic_kernel, dim3((unsigned)(n_hops + n_hops_b)), dim3(256), smem, st, a);
+        WH_LAUNCH_CHECK();
+        return WH_OK;
+    }
     for (long long off = 0; off < n_hops; off += MAXG) {
         long long cnt = n_hops - off < MAXG ? n_hops - off : MAXG;
         a.hop0 = hop0 + off;
@@ -521,7 +532,15 @@ static int pfb_run_fmt(wh_pfb *p, const void *d_iq, int fmt, size_t n, float *d_
     int rc;
     const bool fast = (p->M == FM && p->T == FT);
     long long head = fast ? (H < 8 ? H : 8) : H;
-    if ((rc = launch_generic(p, d_iq, fmt, d_out, 0, head, st)) != WH_OK) return rc;
+    {
+        // head hops (need the carried history) + the <= 3 ragged tail hops of the fast path, one launch
+        long long tail0 = 0, tailn = 0;
+        if (fast && H > 8) {
+            tail0 = 8 + ((H - 8) / GH) * GH;
+            tailn = H - tail0;
+        }
+        if ((rc = launch_generic(p, d_iq, fmt, d_out, 0, head, st, tail0, tailn)) != WH_OK) return rc;
+    }
     if (fast && H > 8) {
         long long n_groups = (H - 8) / GH;
         if (n_groups > 0) {
@@ -557,8 +576,6 @@ static int pfb_run_fmt(wh_pfb *p, const void *d_iq, int fmt, size_t n, float *d_
                 p->ev_valid = true;
             }
         }
-        long long done = 8 + n_groups * GH;
-        if ((rc = launch_generic(p, d_iq, fmt, d_out, done, H - done, st)) != WH_OK) return rc;
     }
     // carry the history
     int nxt = p->cur ^ 1;
@@ -606,8 +623,9 @@ extern "C" int wh_pfb_channel_stats(const float *d_out, size_t hops, int M, doub
     if (!d_out || !d_stats || M < 1) return set_err(WH_E_ARG, "wh_pfb_channel_stats: bad args");
     if (hops == 0) return WH_OK;
     hipStream_t st = as_stream(stream);
-    int slices = (int)((hops + 255) / 256);
+    int slices = (int)((hops + 15) / 16);   // >= 16 hops per slice, up to 64 slices x M/64 column blocks
     if (slices > 64) slices = 64;
+    if (slices < 1) slices = 1;
     double *part = nullptr;
     WH_HIP(hipMallocAsync(reinterpret_cast<void **>(&part), (size_t)slices * M * 4 * sizeof(double), st));
     hipLaunchKernelGGL(pfb_stats_kernel, dim3((M + 63) / 64, slices), dim3(64, 4), 0, st,
