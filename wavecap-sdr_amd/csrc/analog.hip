@@ -39,6 +39,26 @@ __device__ __forceinline__ float2 mix(float2 x, float c, int n, bool do_mix) {
     return make_float2(x.x * co - x.y * s, x.x * s + x.y * co);
 }
 
+// atan2f for the analog chains (tolerance 1e-5, no bit-exactness requirement): same octant reduction
+// and minimax polynomial as whm_atan2f, but v_rcp-based quotients instead of IEEE divisions.
+__device__ __forceinline__ float fast_atan2f(float y, float x) {
+    const float PI_F = 3.14159265358979323846f, PIO2_F = 1.57079632679489661923f, PIO4_F = 0.78539816339744830962f;
+    float ax = fabsf(x), ay = fabsf(y);
+    float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    float t = mx == 0.0f ? 0.0f : mn * __builtin_amdgcn_rcpf(mx);
+    float base = 0.0f;
+    if (t > 0.4142135623730950f) {
+        t = (t - 1.0f) * __builtin_amdgcn_rcpf(t + 1.0f);
+        base = PIO4_F;
+    }
+    float z = t * t;
+    float p = fmaf(fmaf(fmaf(8.05374449538e-2f, z, -1.38776856032e-1f), z, 1.99777106478e-1f), z, -3.33329491539e-1f);
+    float r = base + fmaf(p * z, t, t);
+    if (ay > ax) r = PIO2_F - r;
+    if (x < 0.0f) r = PI_F - r;
+    return y < 0.0f ? -r : r;
+}
+
 __global__ void unpack_kernel(const short2 *in, float2 *out, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -145,8 +165,8 @@ constexpr int FM_MAX_TAPS = 2048;    // float64 taps kept in LDS (16 KiB)
 
 __global__ __launch_bounds__(256) void fmbank_fused_kernel(FmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    double *taps_s = reinterpret_cast<double *>(smem_raw);
-    float *fm_s = reinterpret_cast<float *>(smem_raw + (size_t)a.ntaps * sizeof(double));
+    float *taps_s = reinterpret_cast<float *>(smem_raw);                       // taps rounded to float32
+    float *fm_s = reinterpret_cast<float *>(smem_raw + (size_t)a.ntaps * sizeof(float));
     __shared__ double red[8];
 
     const int tile = blockIdx.x, k = blockIdx.y, chunk = blockIdx.z;
@@ -161,7 +181,7 @@ __global__ __launch_bounds__(256) void fmbank_fused_kernel(FmArgs a) {
     int own_hi = (m0 + a.TO) * a.down;  // exclusive
     if (own_hi > N || m0 + a.TO >= a.n_out) own_hi = N;
 
-    for (int j = tid; j < a.ntaps; j += 256) taps_s[j] = a.taps[j];
+    for (int j = tid; j < a.ntaps; j += 256) taps_s[j] = (float)a.taps[j];
 
     const float c = a.nco_c[k];
     const bool do_mix = c != 0.0f;
@@ -182,7 +202,7 @@ __global__ __launch_bounds__(256) void fmbank_fused_kernel(FmArgs a) {
             if (valid && n >= 1) {
                 float re = bse.x * prv.x + bse.y * prv.y;
                 float im = bse.y * prv.x - bse.x * prv.y;
-                v = whm_atan2f(im, re) * a.scale;
+                v = fast_atan2f(im, re) * a.scale;
             }
             fm_s[i] = v;
             if (valid && n >= own_lo && n < own_hi) {
@@ -210,10 +230,17 @@ __global__ __launch_bounds__(256) void fmbank_fused_kernel(FmArgs a) {
     // phase 2: S = 256/TO lanes share one output; y[m] = sum_j h[j] * fm[(m-m0)*down + ntaps-1-j]
     const int S = 256 / a.TO;
     const int o = tid / S, sub = tid - o * S;
+    // float32 products summed in float32 over blocks of 32 taps, block sums added in float64
+    // (error ~3e-7 of the output scale; scipy accumulates in float64)
     double accv = 0.0;
     if (o < mcnt) {
         const float *f = fm_s + o * a.down + (a.ntaps - 1);
-        for (int j = sub; j < a.ntaps; j += S) accv = fma((double)f[-j], taps_s[j], accv);
+        for (int j0 = sub; j0 < a.ntaps; j0 += 32 * S) {
+            float part = 0.f;
+            int j1 = j0 + 32 * S < a.ntaps ? j0 + 32 * S : a.ntaps;
+            for (int j = j0; j < j1; j += S) part = fmaf(f[-j], taps_s[j], part);
+            accv += (double)part;
+        }
     }
     for (int w = 1; w < S; w <<= 1) accv += __shfl_xor(accv, w);
     if (o < mcnt && sub == 0) a.audio[((size_t)chunk * a.K + k) * a.n_out + m0 + o] = (float)accv;
@@ -572,7 +599,7 @@ extern "C" int wh_chanbank_create(wh_chanbank **out, const wh_chanbank_cfg *c) {
         if (c->ntaps + (TO - 1) * c->down <= FM_MAX_SPAN) {
             b->fused = true;
             b->TO = TO;
-            b->smem = (size_t)c->ntaps * sizeof(double) + (size_t)(c->ntaps + (TO - 1) * c->down) * sizeof(float);
+            b->smem = (size_t)c->ntaps * sizeof(float) + (size_t)(c->ntaps + (TO - 1) * c->down) * sizeof(float);
             WH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fmbank_fused_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->smem));
         }
