@@ -136,8 +136,8 @@ int wh_pfb_extract_channel(const float *d_out, size_t hops, int channel_count, i
 /* A13 activity statistics over a filterbank output block (BinStats fields of
  * channel_classifier.py:17-48 per channel): d_stats float64[M][5] =
  * {sum p, sum p^2, count, min p, max p}, p = |y|^2; accumulate != 0 merges into d_stats. */
-int wh_pfb_channel_stats(const float *d_out, size_t hops, int channel_count, double *d_stats,
-                         int accumulate, void *stream);
+int wh_pfb_channel_stats(wh_pfb *p, const float *d_out, size_t hops, double *d_stats, int accumulate,
+                         void *stream);
 
 /* ---- A8: spectrum, dsp/fft/scipy_backend.py:38-79 ScipyFFTBackend.execute ---------
  * d_iq: complex64, frame f starts at d_iq + f*frame_stride (complex units); uses the

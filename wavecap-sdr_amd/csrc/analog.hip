@@ -15,6 +15,7 @@
 #include "wh_common.h"
 #include "wh_portable_math.h"
 #include <cmath>
+#include <memory>
 #include <vector>
 
 using namespace wh;
@@ -499,10 +500,11 @@ struct wh_resampler {
 extern "C" int wh_resampler_create(wh_resampler **out, const double *h_taps, int ntaps, int up, int down, int d0) {
     if (!out || !h_taps || ntaps < 1 || up < 1 || down < 1) return set_err(WH_E_ARG, "wh_resampler_create: bad args");
     wh_resampler *r = new wh_resampler();
+    std::unique_ptr<wh_resampler, void (*)(wh_resampler *)> guard(r, wh_resampler_destroy);  // frees partial state on early return
     r->ntaps = ntaps; r->up = up; r->down = down; r->d0 = d0;
     WH_HIP(hipMalloc(&r->d_taps, (size_t)ntaps * sizeof(double)));
     WH_HIP(hipMemcpy(r->d_taps, h_taps, (size_t)ntaps * sizeof(double), hipMemcpyHostToDevice));
-    *out = r;
+    *out = guard.release();
     return WH_OK;
 }
 
@@ -556,6 +558,7 @@ extern "C" int wh_chanbank_create(wh_chanbank **out, const wh_chanbank_cfg *c) {
         if (c->h_stages[i].n < 1 || c->h_stages[i].n > MAX_ORD || c->h_stages[i].a[0] == 0.0)
             return set_err(WH_E_ARG, "wh_chanbank_create: bad IIR stage %d", i);
     wh_chanbank *b = new wh_chanbank();
+    std::unique_ptr<wh_chanbank, void (*)(wh_chanbank *)> guard(b, wh_chanbank_destroy);  // frees partial state on early return
     b->cfg = *c;
     b->cfg.h_offsets_hz = nullptr;
     b->cfg.h_taps = nullptr;
@@ -604,7 +607,7 @@ extern "C" int wh_chanbank_create(wh_chanbank **out, const wh_chanbank_cfg *c) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->smem));
         }
     }
-    *out = b;
+    *out = guard.release();
     return WH_OK;
 }
 

@@ -19,6 +19,7 @@
 #include "wh_common.h"
 #include "wh_portable_math.h"
 #include <cmath>
+#include <memory>
 #include <vector>
 
 using namespace wh;
@@ -620,6 +621,7 @@ extern "C" int wh_c4fm_bank_create(wh_c4fm_bank **out, int C, double sps, const 
         n_max > 32000)
         return set_err(WH_E_ARG, "wh_c4fm_bank_create: need sps >= 4, 1 <= max_samples_per_call <= 32000");
     wh_c4fm_bank *b = new wh_c4fm_bank();
+    std::unique_ptr<wh_c4fm_bank, void (*)(wh_c4fm_bank *)> guard(b, wh_c4fm_bank_destroy);  // frees partial state on early return
     b->C = C; b->n_max = n_max; b->nl = nl; b->nr = nr; b->sps = sps;
     int fl = (int)floor(sps);
     b->interp_offset = fl - 4 > 0 ? fl - 4 : 0;
@@ -646,7 +648,7 @@ extern "C" int wh_c4fm_bank_create(wh_c4fm_bank **out, int C, double sps, const 
     int rc = c4fm_zero_state(b, nullptr);
     if (rc != WH_OK) return rc;
     WH_HIP(hipDeviceSynchronize());
-    *out = b;
+    *out = guard.release();
     return WH_OK;
 }
 

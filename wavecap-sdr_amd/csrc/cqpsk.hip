@@ -10,6 +10,7 @@
 //   k_gardner  Gardner TED bank, one lane per channel, float64, bit-exact vs the oracle.
 #include "wh_common.h"
 #include <cmath>
+#include <memory>
 #include <vector>
 
 using namespace wh;
@@ -224,6 +225,7 @@ extern "C" int wh_cqpsk_bank_create(wh_cqpsk_bank **out, int C, double sps, cons
     if (!out || !h_rrc || !h_zi || C < 1 || ntaps < 2 || ntaps > 4096 || !(sps > 1.0) || n_max < 1)
         return set_err(WH_E_ARG, "wh_cqpsk_bank_create: bad arguments");
     wh_cqpsk_bank *b = new wh_cqpsk_bank();
+    std::unique_ptr<wh_cqpsk_bank, void (*)(wh_cqpsk_bank *)> guard(b, wh_cqpsk_bank_destroy);  // frees partial state on early return
     b->C = C; b->n_max = n_max; b->L = ntaps; b->sps = sps;
     b->c_kp = c_kp; b->c_ki = c_ki; b->c_maxf = c_maxf; b->t_kp = t_kp; b->t_ki = t_ki;
     b->zi0.assign(h_zi, h_zi + ntaps - 1);
@@ -237,7 +239,7 @@ extern "C" int wh_cqpsk_bank_create(wh_cqpsk_bank **out, int C, double sps, cons
     WH_HIP(hipMalloc(&b->d_st, (size_t)C * sizeof(CqState)));
     int rc = cq_reset(b, nullptr);
     if (rc != WH_OK) return rc;
-    *out = b;
+    *out = guard.release();
     return WH_OK;
 }
 
@@ -297,10 +299,11 @@ struct wh_gardner_bank {
 extern "C" int wh_gardner_bank_create(wh_gardner_bank **out, int C, double sps, double kp, double ki) {
     if (!out || C < 1 || !(sps > 1.0)) return set_err(WH_E_ARG, "wh_gardner_bank_create: bad arguments");
     wh_gardner_bank *g = new wh_gardner_bank();
+    std::unique_ptr<wh_gardner_bank, void (*)(wh_gardner_bank *)> guard(g, wh_gardner_bank_destroy);  // frees partial state on early return
     g->C = C; g->sps = sps; g->kp = kp; g->ki = ki;
     WH_HIP(hipMalloc(&g->d_st, (size_t)C * sizeof(GState)));
     WH_HIP(hipMemset(g->d_st, 0, (size_t)C * sizeof(GState)));
-    *out = g;
+    *out = guard.release();
     return WH_OK;
 }
 

@@ -21,6 +21,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <memory>
 #include <vector>
 
 using namespace wh;
@@ -409,6 +410,7 @@ extern "C" int wh_pfb_create(wh_pfb **out, int M, int T, const double *h_arms) {
     if (!out || !h_arms || M < 2 || (M & 1) || T < 1 || T > 64) return set_err(WH_E_ARG, "wh_pfb_create: bad M/T");
     if ((size_t)M * 16 > 160 * 1024) return set_err(WH_E_ARG, "wh_pfb_create: M=%d exceeds the LDS-resident limit", M);
     wh_pfb *p = new wh_pfb();
+    std::unique_ptr<wh_pfb, void (*)(wh_pfb *)> guard(p, wh_pfb_destroy);  // frees partial state on early return
     p->M = M; p->T = T;
     if (const char *e = getenv("WH_PFB_GPW")) p->gpw_override = atoi(e);
     if (const char *e = getenv("WH_PFB_ABLATE")) p->ablate = atoi(e);
@@ -436,7 +438,7 @@ extern "C" int wh_pfb_create(wh_pfb **out, int M, int T, const double *h_arms) {
     WH_HIP(hipMemcpy(p->d_tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice));
     WH_HIP(hipMemset(p->d_hist[0], 0, (size_t)M * T * sizeof(float2)));
     WH_HIP(hipMemset(p->d_hist[1], 0, (size_t)M * T * sizeof(float2)));
-    *out = p;
+    *out = guard.release();
     return WH_OK;
 }
 
@@ -618,22 +620,21 @@ extern "C" int wh_pfb_extract_channel(const float *d_out, size_t hops, int M, in
     return WH_OK;
 }
 
-extern "C" int wh_pfb_channel_stats(const float *d_out, size_t hops, int M, double *d_stats, int accumulate,
+extern "C" int wh_pfb_channel_stats(wh_pfb *p, const float *d_out, size_t hops, double *d_stats, int accumulate,
                                     void *stream) {
-    if (!d_out || !d_stats || M < 1) return set_err(WH_E_ARG, "wh_pfb_channel_stats: bad args");
+    if (!p || !d_out || !d_stats) return set_err(WH_E_ARG, "wh_pfb_channel_stats: bad args");
     if (hops == 0) return WH_OK;
+    const int M = p->M;
     hipStream_t st = as_stream(stream);
     int slices = (int)((hops + 15) / 16);   // >= 16 hops per slice, up to 64 slices x M/64 column blocks
     if (slices > 64) slices = 64;
     if (slices < 1) slices = 1;
-    double *part = nullptr;
-    WH_HIP(hipMallocAsync(reinterpret_cast<void **>(&part), (size_t)slices * M * 4 * sizeof(double), st));
+    double *part = p->d_part;   // [64][M][4] workspace owned by the handle (no allocation on the hot path)
     hipLaunchKernelGGL(pfb_stats_kernel, dim3((M + 63) / 64, slices), dim3(64, 4), 0, st,
                        reinterpret_cast<const float2 *>(d_out), hops, M, part, slices);
     WH_LAUNCH_CHECK();
     hipLaunchKernelGGL(pfb_stats_final_kernel, dim3((M + 255) / 256), dim3(256), 0, st, part, slices, M, hops,
                        d_stats, accumulate);
     WH_LAUNCH_CHECK();
-    WH_HIP(hipFreeAsync(part, st));
     return WH_OK;
 }

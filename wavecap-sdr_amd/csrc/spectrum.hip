@@ -3,6 +3,7 @@
 // FFT: LDS Stockham radix-2 for power-of-two sizes, direct DFT otherwise.
 #include "wh_common.h"
 #include <cmath>
+#include <memory>
 #include <vector>
 
 using namespace wh;
@@ -78,6 +79,7 @@ struct wh_spectrum {
 extern "C" int wh_spectrum_create(wh_spectrum **out, int N) {
     if (!out || N < 2 || N > 16384) return set_err(WH_E_ARG, "wh_spectrum_create: fft_size must be in [2, 16384]");
     wh_spectrum *s = new wh_spectrum();
+    std::unique_ptr<wh_spectrum, void (*)(wh_spectrum *)> guard(s, wh_spectrum_destroy);  // frees partial state on early return
     s->N = N;
     int l2 = 0;
     while ((1 << l2) < N) ++l2;
@@ -98,7 +100,7 @@ extern "C" int wh_spectrum_create(wh_spectrum **out, int N) {
     if (s->smem > 64 * 1024)
         WH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(spectrum_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->smem));
-    *out = s;
+    *out = guard.release();
     return WH_OK;
 }
 

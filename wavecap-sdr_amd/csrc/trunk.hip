@@ -12,6 +12,7 @@
 #include "wh_common.h"
 #include "wh_portable_math.h"
 #include <cmath>
+#include <memory>
 #include <vector>
 
 using namespace wh;
@@ -190,6 +191,7 @@ extern "C" int wh_ddc_create(wh_ddc **out, int sample_rate, const double *h_taps
         (d2 > 1 && (!h_taps2 || n2 < 1 || n2 > 4096)))
         return set_err(WH_E_ARG, "wh_ddc_create: bad arguments");
     wh_ddc *d = new wh_ddc();
+    std::unique_ptr<wh_ddc, void (*)(wh_ddc *)> guard(d, wh_ddc_destroy);  // frees partial state on early return
     d->fs = sample_rate; d->L1 = n1; d->D1 = d1; d->L2 = d2 > 1 ? n2 : 0; d->D2 = d2 > 1 ? d2 : 1;
     d->max_n = max_samples_per_call;
     WH_HIP(hipMalloc(&d->d_t1, n1 * sizeof(double)));
@@ -201,7 +203,7 @@ extern "C" int wh_ddc_create(wh_ddc **out, int sample_rate, const double *h_taps
         for (int i = 0; i < 2; ++i) WH_HIP(hipMalloc(&d->d_h2[i], (size_t)(n2 > 1 ? n2 - 1 : 1) * sizeof(float2)));
         WH_HIP(hipMalloc(&d->d_mid, ((size_t)max_samples_per_call / d1 + 2) * sizeof(float2)));
     }
-    *out = d;
+    *out = guard.release();
     return WH_OK;
 }
 

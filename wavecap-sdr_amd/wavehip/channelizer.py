@@ -123,7 +123,7 @@ class PolyphaseChannelizer:
         if stats is None:
             stats = torch.zeros((self.channel_count, 5), dtype=torch.float64, device=out_dev.device)
             accumulate = False
-        _lib.check(_lib.lib.wh_pfb_channel_stats(out_dev.data_ptr(), H, self.channel_count, stats.data_ptr(),
+        _lib.check(_lib.lib.wh_pfb_channel_stats(self._h, out_dev.data_ptr(), H, stats.data_ptr(),
                                                  1 if accumulate else 0, _lib.stream_ptr(torch)),
                    "wh_pfb_channel_stats")
         return stats
