@@ -169,9 +169,13 @@ void wh_ddc_destroy(wh_ddc *d);
 /* ---- A13: control-channel scanner measurement, trunking/cc_scanner.py:165-264 --------------
  * For each candidate offset (already round()ed, 0 = no mix): capture.freq_shift ->
  * lfilter(h_taps float64, zero state) -> [::decim] -> h_out[i] = {mean |y|^2, max |y|^2}
- * (float64).  Synchronous: the scanner consumes the numbers on the host.                   */
+ * (float64).  Synchronous: the scanner consumes the numbers on the host.
+ * h_sync_corr (optional, [n_offsets]): best normalised soft correlation of the decimated stream's
+ * FM-demodulated symbol samples with the P25 frame sync, cc_scanner.py:266-353 (_detect_sync_pattern
+ * returns |corr| > 0.6; the SNR gate and threshold are applied by the host shim).              */
 int wh_scan_measure(const float *d_iq, size_t n, int sample_rate, const int *h_offsets_hz, int n_offsets,
-                    const double *h_taps, int ntaps, int decim, double *h_out, void *stream);
+                    const double *h_taps, int ntaps, int decim, double *h_out, double *h_sync_corr,
+                    void *stream);
 
 /* ---- A9-A11: P25 C4FM demodulator bank, dsp/p25/c4fm.py:2379-2807 ------------------
  * One independent C4FMDemodulator per channel (ctor c4fm.py:2412-2503).  Filters are

@@ -335,6 +335,15 @@ def gen_trunk():
     out["scan_offsets"] = np.array([f - center for f in chans])
     out["scan_meas"] = np.array([[m.power_db, m.peak_power_db, m.noise_floor_db, m.snr_db, m.sample_count]
                                  for m in meas])
+    # sync-pattern check (cc_scanner.py:266-353): a real C4FM control channel at +300 kHz, a CW at -450 kHz
+    w2 = (S.c4fm_iq(n, fs, 1300, snr_db=30.0, freq_offset_hz=300e3, amp=0.2)[0]
+          + (0.05 * np.exp(2j * np.pi * -450e3 * t)).astype(np.complex64)).astype(np.complex64)
+    sc2 = ControlChannelScanner(center_hz=center, sample_rate=fs, control_channels=chans, sync_check_enabled=True)
+    meas2 = [sc2._measure_channel(w2, f) for f in chans]
+    out["scan2_sha"] = np.array(S.sha256(w2))
+    out["scan2_meas"] = np.array([[m.power_db, m.peak_power_db, m.noise_floor_db, m.snr_db, float(m.sync_detected)]
+                                  for m in meas2])
+    print("  scanner sync flags:", [m.sync_detected for m in meas2], [round(m.snr_db, 1) for m in meas2])
     save("trunk", **out)
 
 

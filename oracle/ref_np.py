@@ -609,7 +609,30 @@ def scanner_power(iq: np.ndarray, sample_rate: int, offsets_hz) -> np.ndarray:
     return out
 
 
-def scanner_measure(iq: np.ndarray, sample_rate: int, channel_offsets_hz) -> list:
+def scanner_sync_correlation(y: np.ndarray) -> float:
+    """cc_scanner.py:266-353 on one decimated (complex128) stream: best normalised correlation of the
+    FM-demodulated symbol samples (10 samples/symbol, taken at 5::10) with the +-0.2356 sync waveform."""
+    sync = np.array([1, 1, 1, 1, 1, 3, 1, 1, 3, 3, 1, 1, 3, 3, 3, 3, 1, 3, 1, 3, 3, 3, 3, 3])
+    if len(y) < 10 * 24 + 10:
+        return 0.0
+    fm = np.angle(y[1:] * np.conj(y[:-1]))
+    symbols_count = len(fm) // 10
+    if symbols_count < 24:
+        return 0.0
+    ss = fm[5::10][:symbols_count]
+    wave = np.where(sync == 1, 0.2356, -0.2356)
+    search_len = min(len(ss) - 24, symbols_count - 24)
+    best = 0.0
+    norm_sync = np.sqrt(np.sum(wave ** 2))
+    for i in range(max(0, search_len)):
+        w = ss[i:i + 24]
+        c = np.sum(w * wave) / (np.sqrt(np.sum(w ** 2) + 1e-10) * norm_sync)
+        if abs(c) > abs(best):
+            best = c
+    return float(best)
+
+
+def scanner_measure(iq: np.ndarray, sample_rate: int, channel_offsets_hz, sync_check: bool = False) -> list:
     max_offset = sample_rate / 2 - 15000
     edges = [-max_offset + 25000, max_offset - 25000]
     p = scanner_power(iq, sample_rate, list(channel_offsets_hz) + edges)
@@ -619,6 +642,14 @@ def scanner_measure(iq: np.ndarray, sample_rate: int, channel_offsets_hz) -> lis
     for i in range(len(channel_offsets_hz)):
         pw = 10 * np.log10(p[i, 0] + eps)
         nf = 10 * np.log10(noise + eps)
-        res.append(dict(power_db=float(pw), peak_power_db=float(10 * np.log10(p[i, 1] + eps)),
-                        noise_floor_db=float(nf), snr_db=float(pw - nf)))
+        m = dict(power_db=float(pw), peak_power_db=float(10 * np.log10(p[i, 1] + eps)),
+                 noise_floor_db=float(nf), snr_db=float(pw - nf))
+        if sync_check:
+            D = max(1, sample_rate // 48000)
+            taps = _sig.firwin(65, 0.8 / D, window=("kaiser", 6.0))
+            sft = freq_shift(iq, float(channel_offsets_hz[i]), sample_rate)
+            y = np.convolve(sft.astype(np.complex128), taps)[: len(sft)][::D]
+            m["sync_correlation"] = scanner_sync_correlation(y)
+            m["sync_detected"] = bool(m["snr_db"] >= 8.0 and abs(m["sync_correlation"]) > 0.6)
+        res.append(m)
     return res

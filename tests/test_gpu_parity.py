@@ -368,3 +368,14 @@ def test_a13_scanner_measure(wh, golden, O):
     assert np.array_equal(got[:, 4], g["scan_meas"][:, 4])
     order = np.argsort(-got[:, 3])
     assert order[0] == 0 and order[1] == 1            # the two carriers rank first by SNR
+    # sync-pattern check on a buffer with a real C4FM carrier: flags == reference, correlation ~ oracle
+    from test_oracle_golden import _scan_buffer2
+    w2 = _scan_buffer2(n, fs)
+    offs = [float(v) for v in g["scan_offsets"]]
+    res2 = wh.ScannerMeasure(fs).measure(w2, offs)
+    ref2 = O.scanner_measure(w2, fs, offs, sync_check=True)
+    got2 = np.array([[m["power_db"], m["peak_power_db"], m["noise_floor_db"], m["snr_db"]] for m in res2])
+    assert np.allclose(got2, g["scan2_meas"][:, :4], atol=2e-4)
+    assert [float(m["sync_detected"]) for m in res2] == list(g["scan2_meas"][:, 4])
+    for a, b in zip(res2, ref2):
+        assert abs(a["sync_correlation"] - b["sync_correlation"]) <= 1e-6

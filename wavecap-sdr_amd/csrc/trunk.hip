@@ -154,6 +154,79 @@ __global__ __launch_bounds__(256) void scan_measure_kernel(ScanArgs a) {
     }
 }
 
+// ---- sync-pattern check of cc_scanner.py:266-353 ---------------------------------------------
+// symbol_samples[k] = angle(y[j+1] * conj(y[j])), j = 5 + 10 k, y = the decimated complex128 stream of
+// scan_measure (only the two y values per symbol that are needed get evaluated).
+__global__ __launch_bounds__(256) void scan_symbols_kernel(ScanArgs a, double *sym /*[n_off][n_sym]*/, int n_sym) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm_raw[];
+    double *tp = reinterpret_cast<double *>(sm_raw);
+    const int tid = threadIdx.x, off = blockIdx.y;
+    for (int i = tid; i < a.L; i += 256) tp[i] = a.taps[i];
+    __syncthreads();
+    const int k = blockIdx.x * 256 + tid;
+    if (k >= n_sym) return;
+    const float c = a.nco_c[off];
+    const bool do_mix = c != 0.0f;
+    double yr[2], yi[2];
+    for (int e = 0; e < 2; ++e) {
+        const long long p = (long long)(5 + 10 * k + e) * a.D;
+        double ar = 0.0, ai = 0.0;
+        for (int t = 0; t < a.L; ++t) {
+            long long q = p - t;
+            if (q < 0) break;
+            float2 v = a.x[q];
+            if (do_mix) {
+                float ph = __fmul_rn(c, (float)q);
+                float sn, cs;
+                whm_sincos_phase(ph, &sn, &cs);
+                v = make_float2(v.x * cs - v.y * sn, v.x * sn + v.y * cs);
+            }
+            ar = fma(tp[t], (double)v.x, ar);
+            ai = fma(tp[t], (double)v.y, ai);
+        }
+        yr[e] = ar; yi[e] = ai;
+    }
+    // y[j+1] * conj(y[j])
+    double re = yr[1] * yr[0] + yi[1] * yi[0];
+    double im = yi[1] * yr[0] - yr[1] * yi[0];
+    sym[(size_t)off * n_sym + k] = atan2(im, re);
+}
+
+// best normalised correlation against the +-0.2356 sync waveform over all window positions
+__global__ __launch_bounds__(256) void scan_sync_kernel(const double *sym, int n_sym, int search_len, double *best_out) {
+    const int off = blockIdx.x, tid = threadIdx.x;
+    const double *s = sym + (size_t)off * n_sym;
+    const unsigned long long PAT = 0x5575F5FF77FFULL;   // dibit 1 -> +dev, dibit 3 -> -dev
+    const double DEV = 0.2356;
+    const double norm_sync = sqrt(24.0 * DEV * DEV);
+    double best = 0.0;
+    int best_i = 0x7fffffff;
+    for (int i = tid; i < search_len; i += 256) {
+        double dot = 0.0, nn = 0.0;
+        for (int j = 0; j < 24; ++j) {
+            double w = s[i + j];
+            double sw = ((PAT >> ((23 - j) * 2)) & 3ULL) == 1ULL ? DEV : -DEV;
+            dot += w * sw;
+            nn += w * w;
+        }
+        double corr = dot / (sqrt(nn + 1e-10) * norm_sync);
+        if (fabs(corr) > fabs(best)) { best = corr; best_i = i; }   // i increases per thread: first max kept
+    }
+    __shared__ double sb[256];
+    __shared__ int si[256];
+    sb[tid] = best; si[tid] = best_i;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (tid < st) {
+            double o = sb[tid + st];
+            int oi = si[tid + st];
+            if (fabs(o) > fabs(sb[tid]) || (fabs(o) == fabs(sb[tid]) && oi < si[tid])) { sb[tid] = o; si[tid] = oi; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) best_out[off] = sb[0];
+}
+
 __global__ void scan_final_kernel(const double *part, int blocks, int n_off, int n_out, double *out) {
     int off = blockIdx.x * blockDim.x + threadIdx.x;
     if (off >= n_off) return;
@@ -287,7 +360,7 @@ extern "C" int wh_ddc_run(wh_ddc *d, const float *d_iq, size_t n, double offset_
 
 extern "C" int wh_scan_measure(const float *d_iq, size_t n, int sample_rate, const int *h_offsets_hz, int n_off,
                                const double *h_taps, int ntaps, int decim, double *h_out /* [n_off][2] */,
-                               void *stream) {
+                               double *h_sync_corr /* [n_off] or NULL */, void *stream) {
     if (!d_iq || !h_offsets_hz || !h_taps || !h_out || n == 0 || n_off < 1 || n_off > 65535 || ntaps < 1 ||
         ntaps > 4096 || decim < 1 || n > (size_t)1 << 24)
         return set_err(WH_E_ARG, "wh_scan_measure: bad arguments");
@@ -315,7 +388,29 @@ extern "C" int wh_scan_measure(const float *d_iq, size_t n, int sample_rate, con
     hipLaunchKernelGGL(scan_final_kernel, dim3((n_off + 63) / 64), dim3(64), 0, st, d_part, blocks, n_off, n_out, d_res);
     WH_LAUNCH_CHECK();
     WH_HIP(hipMemcpyAsync(h_out, d_res, (size_t)n_off * 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+    double *d_sym = nullptr, *d_best = nullptr;
+    if (h_sync_corr) {
+        // cc_scanner.py:289-325: 10 samples/symbol, fm = angle(y[1:] conj y[:-1]), symbols at 5::10
+        for (int i = 0; i < n_off; ++i) h_sync_corr[i] = 0.0;
+        const int fm_len = n_out - 1;
+        const int symbols_count = fm_len / 10;
+        const int have = fm_len > 5 ? (fm_len - 5 + 9) / 10 : 0;
+        const int n_sym = have < symbols_count ? have : symbols_count;
+        const int search_len = n_sym - 24;           // min(len(symbol_samples) - 24, symbols_count - 24)
+        if (n_out >= 10 * 24 + 10 && symbols_count >= 24 && search_len > 0) {
+            WH_HIP(hipMallocAsync(reinterpret_cast<void **>(&d_sym), (size_t)n_off * n_sym * sizeof(double), st));
+            WH_HIP(hipMallocAsync(reinterpret_cast<void **>(&d_best), (size_t)n_off * sizeof(double), st));
+            hipLaunchKernelGGL(scan_symbols_kernel, dim3((n_sym + 255) / 256, n_off), dim3(256), ntaps * sizeof(double), st,
+                               a, d_sym, n_sym);
+            WH_LAUNCH_CHECK();
+            hipLaunchKernelGGL(scan_sync_kernel, dim3(n_off), dim3(256), 0, st, d_sym, n_sym, search_len, d_best);
+            WH_LAUNCH_CHECK();
+            WH_HIP(hipMemcpyAsync(h_sync_corr, d_best, (size_t)n_off * sizeof(double), hipMemcpyDeviceToHost, st));
+        }
+    }
     WH_HIP(hipStreamSynchronize(st));   // results are host scalars (the scanner picks a channel with them)
+    if (d_sym) WH_HIP(hipFreeAsync(d_sym, st));
+    if (d_best) WH_HIP(hipFreeAsync(d_best, st));
     WH_HIP(hipFreeAsync(d_taps, st));
     WH_HIP(hipFreeAsync(d_nco, st));
     WH_HIP(hipFreeAsync(d_part, st));

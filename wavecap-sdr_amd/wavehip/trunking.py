@@ -91,41 +91,46 @@ class TrunkingDDC:
 class ScannerMeasure:
     """cc_scanner.py:165-264 for a list of candidate offsets of one wideband buffer."""
 
-    def __init__(self, sample_rate: int):
+    def __init__(self, sample_rate: int, sync_check_enabled: bool = True):
         self._torch = _lib.require_gpu()
         self.sample_rate = int(sample_rate)
+        self.sync_check_enabled = sync_check_enabled
         self.decim = max(1, self.sample_rate // 48000)
         self.taps = np.ascontiguousarray(
             signal.firwin(65, 0.8 / self.decim, window=("kaiser", 6.0)) if self.decim > 1 else np.ones(1),
             dtype=np.float64)
 
-    def power(self, iq_dev, offsets_hz) -> np.ndarray:
-        """-> float64 [n, 2] = (mean |y|^2, max |y|^2) per offset."""
+    def power(self, iq_dev, offsets_hz, want_sync: bool = False):
+        """-> float64 [n, 2] = (mean |y|^2, max |y|^2) per offset (and the best sync correlation [n])."""
         torch = self._torch
         assert iq_dev.is_cuda and iq_dev.dtype == torch.complex64 and iq_dev.is_contiguous()
         offs = np.array([int(round(float(o))) if float(o) != 0.0 else 0 for o in offsets_hz], dtype=np.int32)
         out = np.zeros((len(offs), 2), dtype=np.float64)
+        corr = np.zeros(len(offs), dtype=np.float64)
         _lib.check(_lib.lib.wh_scan_measure(iq_dev.data_ptr(), iq_dev.numel(), self.sample_rate, _lib.dptr(offs, "i32"),
                                             len(offs), _lib.dptr(self.taps, "f64"), len(self.taps), self.decim,
-                                            out.ctypes.data_as(C.POINTER(C.c_double)), _lib.stream_ptr(torch)),
-                   "wh_scan_measure")
-        return out
+                                            out.ctypes.data_as(C.POINTER(C.c_double)),
+                                            corr.ctypes.data_as(C.POINTER(C.c_double)) if want_sync else None,
+                                            _lib.stream_ptr(torch)), "wh_scan_measure")
+        return (out, corr) if want_sync else out
 
     def measure(self, iq, channel_offsets_hz) -> list[dict]:
-        """Per candidate: power_db, peak_power_db, noise_floor_db, snr_db, sample_count -- the fields of
-        ChannelMeasurement (cc_scanner.py:240-264); sync detection is not part of this operator."""
+        """Per candidate: power_db, peak_power_db, noise_floor_db, snr_db, sync_detected, sample_count -- the
+        fields of ChannelMeasurement (cc_scanner.py:240-264)."""
         torch = self._torch
         x = iq if torch.is_tensor(iq) else torch.from_numpy(np.ascontiguousarray(iq, dtype=np.complex64)).cuda()
         max_offset = self.sample_rate / 2 - 15000
         edges = [-max_offset + 25000, max_offset - 25000]
-        p = self.power(x, list(channel_offsets_hz) + edges)
+        p, corr = self.power(x, list(channel_offsets_hz) + edges, want_sync=True)
         noise = min(p[-2, 0], p[-1, 0])
         eps = 1e-12
         out = []
         for i in range(len(channel_offsets_hz)):
             pw = 10 * np.log10(p[i, 0] + eps)
             nf = 10 * np.log10(noise + eps)
+            snr = float(pw - nf)
+            sync = bool(self.sync_check_enabled and snr >= 8.0 and abs(corr[i]) > 0.6)   # cc_scanner.py:247-251, 345-350
             out.append(dict(power_db=float(pw), peak_power_db=float(10 * np.log10(p[i, 1] + eps)),
-                            noise_floor_db=float(nf), snr_db=float(pw - nf),
+                            noise_floor_db=float(nf), snr_db=snr, sync_detected=sync, sync_correlation=float(corr[i]),
                             sample_count=(x.numel() + self.decim - 1) // self.decim))
         return out
