@@ -147,6 +147,11 @@ typedef struct wh_spectrum wh_spectrum;
 int wh_spectrum_create(wh_spectrum **out, int fft_size);
 int wh_spectrum_run(wh_spectrum *s, const float *d_iq, size_t n_frames, size_t frame_stride,
                     float *d_power_db, void *stream);
+/* rocFFT engine: window prologue -> (rocFFT C2C forward of length fft_size, batched, run by the caller's
+ * binding) -> |X| / fftshift / 20 log10 epilogue.  d_windowed, d_fft: complex64 [n_frames][fft_size]. */
+int wh_spectrum_window(wh_spectrum *s, const float *d_iq, size_t n_frames, size_t frame_stride,
+                       float *d_windowed, void *stream);
+int wh_spectrum_post(wh_spectrum *s, const float *d_fft, size_t n_frames, float *d_power_db, void *stream);
 void wh_spectrum_destroy(wh_spectrum *s);
 
 void wh_pfb_destroy(wh_pfb *p);

@@ -67,6 +67,30 @@ __global__ __launch_bounds__(256) void spectrum_kernel(const float2 *iq, size_t 
     }
 }
 
+// rocFFT engine helpers: the FFT itself is rocFFT (through the caller's binding); these two kernels are
+// the fused prologue (window) and epilogue (|X|, fftshift, 20 log10) around it.
+__global__ __launch_bounds__(256) void spectrum_window_kernel(const float2 *iq, size_t frame_stride, float2 *out,
+                                                              const float *window, int N, size_t total) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    size_t f = i / N;
+    int n = (int)(i - f * N);
+    float2 v = iq[f * frame_stride + n];
+    float w = window[n];
+    out[i] = make_float2(v.x * w, v.y * w);
+}
+
+__global__ __launch_bounds__(256) void spectrum_post_kernel(const float2 *X, float *out, int N, size_t total) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    size_t f = i / N;
+    int b = (int)(i - f * N);
+    int k = b + (N - N / 2);
+    if (k >= N) k -= N;
+    float2 v = X[f * N + k];
+    out[i] = 20.0f * log10f(sqrtf(v.x * v.x + v.y * v.y) + 1e-10f);
+}
+
 }  // namespace
 
 struct wh_spectrum {
@@ -120,6 +144,28 @@ extern "C" int wh_spectrum_run(wh_spectrum *s, const float *d_iq, size_t n_frame
     hipLaunchKernelGGL(spectrum_kernel, dim3((unsigned)n_frames), dim3(256), s->smem, as_stream(stream),
                        reinterpret_cast<const float2 *>(d_iq), frame_stride, d_power_db, s->d_window, s->d_tw, s->N,
                        s->log2N);
+    WH_LAUNCH_CHECK();
+    return WH_OK;
+}
+
+extern "C" int wh_spectrum_window(wh_spectrum *s, const float *d_iq, size_t n_frames, size_t frame_stride,
+                                  float *d_windowed, void *stream) {
+    if (!s || !d_iq || !d_windowed) return set_err(WH_E_ARG, "wh_spectrum_window: null");
+    if (n_frames == 0) return WH_OK;
+    size_t total = n_frames * (size_t)s->N;
+    hipLaunchKernelGGL(spectrum_window_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float2 *>(d_iq), frame_stride, reinterpret_cast<float2 *>(d_windowed),
+                       s->d_window, s->N, total);
+    WH_LAUNCH_CHECK();
+    return WH_OK;
+}
+
+extern "C" int wh_spectrum_post(wh_spectrum *s, const float *d_fft, size_t n_frames, float *d_power_db, void *stream) {
+    if (!s || !d_fft || !d_power_db) return set_err(WH_E_ARG, "wh_spectrum_post: null");
+    if (n_frames == 0) return WH_OK;
+    size_t total = n_frames * (size_t)s->N;
+    hipLaunchKernelGGL(spectrum_post_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float2 *>(d_fft), d_power_db, s->N, total);
     WH_LAUNCH_CHECK();
     return WH_OK;
 }

@@ -94,6 +94,8 @@ PROTOTYPES = {
     "wh_pfb_destroy": (None, [c_void_p]),
     "wh_spectrum_create": (c_int, [C.POINTER(c_void_p), c_int]),
     "wh_spectrum_run": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p]),
+    "wh_spectrum_window": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p]),
+    "wh_spectrum_post": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "wh_spectrum_destroy": (None, [c_void_p]),
     "wh_ddc_create": (c_int, [C.POINTER(c_void_p), c_int, C.POINTER(c_double), c_int, c_int, C.POINTER(c_double),
                               c_int, c_int, c_int]),

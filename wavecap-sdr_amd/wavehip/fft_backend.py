@@ -67,7 +67,13 @@ def is_available() -> bool:
 class HipFFTBackend(FFTBackend):
     """MI355X spectrum backend (window + FFT + |.| + fftshift + log10 fused in one HIP kernel)."""
 
-    def __init__(self, fft_size: int = 2048):
+    def __init__(self, fft_size: int = 2048, engine: str = "fused"):
+        """engine "fused": one HIP kernel per frame (window, LDS FFT, |.|, shift, log).
+        engine "rocfft": HIP window kernel -> rocFFT batched C2C (reached through torch.fft, which is
+        hipFFT/rocFFT on ROCm) -> HIP epilogue kernel; the form BASELINE.json's north_star names."""
+        if engine not in ("fused", "rocfft"):
+            raise ValueError("engine must be 'fused' or 'rocfft'")
+        self.engine = engine
         try:
             from . import _lib
             import torch
@@ -103,6 +109,14 @@ class HipFFTBackend(FFTBackend):
         assert iq_dev.is_cuda and iq_dev.dtype == torch.complex64 and iq_dev.is_contiguous()
         assert iq_dev.numel() >= (n_frames - 1) * stride + N
         out = torch.empty((n_frames, N), dtype=torch.float32, device=iq_dev.device)
+        if self.engine == "rocfft":
+            w = torch.empty((n_frames, N), dtype=torch.complex64, device=iq_dev.device)
+            self._lib.check(self._lib.lib.wh_spectrum_window(self._h, iq_dev.data_ptr(), n_frames, stride, w.data_ptr(),
+                                                             self._lib.stream_ptr(torch)), "wh_spectrum_window")
+            X = torch.fft.fft(w, dim=1)          # rocFFT, batched C2C forward
+            self._lib.check(self._lib.lib.wh_spectrum_post(self._h, X.data_ptr(), n_frames, out.data_ptr(),
+                                                           self._lib.stream_ptr(torch)), "wh_spectrum_post")
+            return out
         self._lib.check(self._lib.lib.wh_spectrum_run(self._h, iq_dev.data_ptr(), n_frames, stride, out.data_ptr(),
                                                       self._lib.stream_ptr(torch)), "wh_spectrum_run")
         return out
