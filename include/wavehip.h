@@ -110,6 +110,13 @@ int wh_chanbank_run(wh_chanbank *b, const void *d_in, size_t n_chunks, float *d_
 size_t wh_chanbank_workspace_bytes(const wh_chanbank *b, size_t n_chunks);
 void wh_chanbank_destroy(wh_chanbank *b);
 
+/* ---- N1: Channel.update_signal_metrics, capture.py:749-798, for K channels of one chunk -----------
+ * h_out float32 [K][3] = {rssi_db, |base| of rank n//10, |base| of rank n - n//10 - 1}: the RSSI and the
+ * two exact order statistics the reference takes with np.partition (noise floor / signal peak).
+ * Synchronous (returns host scalars).                                                         */
+int wh_channel_signal_metrics(const void *d_in, int input_format, size_t n, int sample_rate,
+                              const int *h_offsets_hz, int n_channels, float *h_out, void *stream);
+
 /* ---- A7: polyphase channelizer, dsp/channelizer.py:28-158 PolyphaseChannelizer ----
  * h_arms: float64[M][T] exactly as _design_filter builds them (channelizer.py:69-89).
  * run(): processes (n-M)/(M/2)+1 hops, writes complex64 d_out[hops][M] (row h == the

@@ -174,6 +174,18 @@ def gen_chain():
                                               enable_deemphasis=True, enable_mpx_filter=False, enable_fm_highpass=True,
                                               fm_highpass_hz=300, enable_fm_lowpass=True, fm_lowpass_hz=3000,
                                               notch_frequencies=[1000.0]))
+    # N1: Channel.update_signal_metrics on config-2 content (10 calls -> the SNR branch runs on the 10th)
+    iq = S.nbfm_bank_c64(n, fs, seed=500, start=0)
+    offs_all = S.nbfm_bank_offsets()
+    mets = []
+    for k in (0, 13, 31):
+        chn = rc.Channel(cfg=_cfg("nbfm", offs_all[k]))
+        chn.state = "running"
+        for _ in range(10):
+            rc._get_freq_shift_exp.cache_clear()
+            chn.update_signal_metrics(iq, fs)
+        mets.append([chn.rssi_db, chn.snr_db])
+    out["sigmet"] = np.array(mets)
     save("chain_analog", **out)
 
 

@@ -431,6 +431,22 @@ def process_channel(samples: np.ndarray, sample_rate: int, offset_hz: float, dem
     return audio, metrics
 
 
+def update_signal_metrics(iq: np.ndarray, sample_rate: int, offset_hz: float):
+    """Channel.update_signal_metrics, capture.py:749-798 (the every-10th-call SNR branch taken)."""
+    shifted = iq if offset_hz == 0.0 else freq_shift(iq, offset_hz, sample_rate)
+    mag = np.abs(shifted)
+    rssi = float(10.0 * np.log10(np.mean(mag ** 2) + 1e-10))
+    n = mag.size
+    k_noise, k_signal = n // 10, n - n // 10 - 1
+    snr = None
+    if k_noise > 0 and k_signal > k_noise:
+        part = np.partition(mag, [k_noise, k_signal])
+        noise_power, signal_power = part[k_noise] ** 2, part[k_signal] ** 2
+        if noise_power > 1e-10:
+            snr = float(10.0 * np.log10(signal_power / noise_power))
+    return rssi, snr
+
+
 # --------------------------------------------------------------------------
 # A7  2x-oversampled polyphase filterbank
 # --------------------------------------------------------------------------

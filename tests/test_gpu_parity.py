@@ -169,6 +169,27 @@ def test_chain_nbfm_multichunk_matches_single(wh):
         assert np.array_equal(a1.cpu().numpy()[0], a3[c])
 
 
+def test_n1_signal_metrics(wh, golden, O):
+    """Channel.update_signal_metrics for all 32 channels in one pass: RSSI + exact 10/90-percentile SNR."""
+    g = golden("chain_analog")
+    fs, n, seed0 = (int(v) for v in g["nbfm_args"])
+    iq = S.nbfm_bank_c64(n, fs, seed=seed0, start=0)
+    offs = S.nbfm_bank_offsets()
+    res = wh.update_signal_metrics(iq, fs, offs)
+    for row, k in zip(g["sigmet"], (0, 13, 31)):
+        assert abs(res[k]["rssi_db"] - row[0]) <= 2e-4 and abs(res[k]["snr_db"] - row[1]) <= 2e-4
+    for k in (5, 20):
+        rssi, snr = O.update_signal_metrics(iq, fs, offs[k])
+        assert abs(res[k]["rssi_db"] - rssi) <= 2e-4 and abs(res[k]["snr_db"] - snr) <= 2e-4
+    # int16 input and a zero offset (no mix)
+    i16 = S.pack_iq16_np(iq)
+    r2 = wh.update_signal_metrics(i16, fs, [0.0, offs[3]], input_format="int16")
+    z = O.unpack_iq16(i16)
+    for got, off in zip(r2, (0.0, offs[3])):
+        rssi, snr = O.update_signal_metrics(z, fs, off)
+        assert abs(got["rssi_db"] - rssi) <= 2e-4 and abs(got["snr_db"] - snr) <= 2e-4
+
+
 def test_chain_wbfm(wh, golden):
     g = golden("chain_analog")
     for ci in range(2):

@@ -427,6 +427,49 @@ __global__ __launch_bounds__(256) void fmbank_finalize_kernel(float *audio, cons
     }
 }
 
+// exact k-th smallest of a row of non-negative floats (np.partition semantics, capture.py:781-788):
+// 3-pass radix select on the IEEE bit patterns (monotonic for x >= 0): 11 + 11 + 10 bits, LDS histograms.
+__global__ __launch_bounds__(256) void select_kth_kernel(const float *rows, int N, int k_lo, int k_hi, float *out) {
+    __shared__ unsigned hist[2048];
+    __shared__ unsigned s_prefix, s_rank;
+    const int row = blockIdx.x, which = blockIdx.y, tid = threadIdx.x;
+    const unsigned *r = reinterpret_cast<const unsigned *>(rows + (size_t)row * N);
+    unsigned prefix = 0, rank = (unsigned)(which == 0 ? k_lo : k_hi);
+    const int shifts[3] = {21, 10, 0};
+    const int widths[3] = {11, 11, 10};
+    for (int pass = 0; pass < 3; ++pass) {
+        const int sh = shifts[pass], nb = 1 << widths[pass];
+        for (int i = tid; i < 2048; i += 256) hist[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < N; i += 256) {
+            unsigned b = r[i] & 0x7fffffffu;    // |x| (inputs are magnitudes; -0 -> +0)
+            bool match = pass == 0 || (b >> (sh + widths[pass])) == prefix;
+            if (match) atomicAdd(&hist[(b >> sh) & (nb - 1)], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned acc = 0;
+            int bin = 0;
+            for (; bin < nb; ++bin) {
+                if (acc + hist[bin] > rank) break;
+                acc += hist[bin];
+            }
+            s_prefix = (prefix << widths[pass]) | (unsigned)bin;
+            s_rank = rank - acc;
+        }
+        __syncthreads();
+        prefix = s_prefix;
+        rank = s_rank;
+        __syncthreads();
+    }
+    if (tid == 0) out[row * 2 + which] = __uint_as_float(prefix);
+}
+
+__global__ void metrics_rssi_kernel(const double *acc, int rows, int N, float *out) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < rows) out[r] = (float)(10.0 * log10(acc[(size_t)r * 2] / (double)N + 1e-10));
+}
+
 inline unsigned grid_for(size_t n) {
     size_t g = (n + 255) / 256;
     return (unsigned)(g > 4096 ? 4096 : (g ? g : 1));
@@ -698,5 +741,54 @@ extern "C" int wh_chanbank_run(wh_chanbank *b, const void *d_in, size_t n_chunks
     hipLaunchKernelGGL(fmbank_finalize_kernel, dim3((unsigned)rows), dim3(256), 0, st, d_audio, b->d_acc, d_metrics,
                        c.chunk_len, c.n_out, b->post);
     WH_LAUNCH_CHECK();
+    return WH_OK;
+}
+
+/* Channel.update_signal_metrics (capture.py:749-798) for K channels of one chunk: h_out[k] =
+ * {rssi_db, |x| at rank n//10, |x| at rank n - n//10 - 1} (the two order statistics the reference takes
+ * with np.partition; the host shim turns them into snr_db). */
+extern "C" int wh_channel_signal_metrics(const void *d_in, int input_format, size_t n, int sample_rate,
+                                         const int *h_offsets_hz, int K, float *h_out, void *stream) {
+    if (!d_in || !h_offsets_hz || !h_out || n < 2 || n > ((size_t)1 << 24) || K < 1 || K > 65535 ||
+        (input_format != 0 && input_format != 1))
+        return set_err(WH_E_ARG, "wh_channel_signal_metrics: bad arguments");
+    hipStream_t st = as_stream(stream);
+    std::vector<float> nco(K);
+    for (int k = 0; k < K; ++k) nco[k] = h_offsets_hz[k] == 0 ? 0.0f : nco_const(h_offsets_hz[k], sample_rate);
+    float *d_nco = nullptr, *d_rows = nullptr, *d_sel = nullptr, *d_rssi = nullptr;
+    double *d_acc = nullptr;
+    WH_HIP(hipMallocAsync(reinterpret_cast<void **>(&d_nco), K * sizeof(float), st));
+    WH_HIP(hipMallocAsync(reinterpret_cast<void **>(&d_rows), (size_t)K * n * sizeof(float), st));
+    WH_HIP(hipMallocAsync(reinterpret_cast<void **>(&d_sel), (size_t)K * 2 * sizeof(float), st));
+    WH_HIP(hipMallocAsync(reinterpret_cast<void **>(&d_rssi), (size_t)K * sizeof(float), st));
+    WH_HIP(hipMallocAsync(reinterpret_cast<void **>(&d_acc), (size_t)K * 2 * sizeof(double), st));
+    WH_HIP(hipMemcpyAsync(d_nco, nco.data(), K * sizeof(float), hipMemcpyHostToDevice, st));
+    WH_HIP(hipMemsetAsync(d_acc, 0, (size_t)K * 2 * sizeof(double), st));
+    FmArgs a;
+    a.in = d_in; a.audio = nullptr; a.acc = d_acc; a.fm_out = d_rows; a.nco_c = d_nco; a.taps = nullptr;
+    a.fmt = input_format; a.N = (int)n; a.K = K; a.n_out = 0; a.ntaps = 0; a.down = 1; a.d0 = 0; a.TO = 1;
+    a.scale = 0.f; a.demod = 1; a.bfo_c = 0.0; a.fs_d = (double)sample_rate;
+    const int per_block = 4 * 63 * 16;
+    hipLaunchKernelGGL(chan_front_kernel, dim3((unsigned)((n + per_block - 1) / per_block), K, 1), dim3(256), 0, st, a);
+    WH_LAUNCH_CHECK();
+    const int k_lo = (int)(n / 10), k_hi = (int)(n - n / 10 - 1);
+    hipLaunchKernelGGL(select_kth_kernel, dim3(K, 2), dim3(256), 0, st, d_rows, (int)n, k_lo, k_hi, d_sel);
+    WH_LAUNCH_CHECK();
+    hipLaunchKernelGGL(metrics_rssi_kernel, dim3((K + 63) / 64), dim3(64), 0, st, d_acc, K, (int)n, d_rssi);
+    WH_LAUNCH_CHECK();
+    std::vector<float> sel((size_t)K * 2), rssi(K);
+    WH_HIP(hipMemcpyAsync(sel.data(), d_sel, sel.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+    WH_HIP(hipMemcpyAsync(rssi.data(), d_rssi, rssi.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+    WH_HIP(hipStreamSynchronize(st));
+    for (int k = 0; k < K; ++k) {
+        h_out[k * 3] = rssi[k];
+        h_out[k * 3 + 1] = sel[k * 2];
+        h_out[k * 3 + 2] = sel[k * 2 + 1];
+    }
+    WH_HIP(hipFreeAsync(d_nco, st));
+    WH_HIP(hipFreeAsync(d_rows, st));
+    WH_HIP(hipFreeAsync(d_sel, st));
+    WH_HIP(hipFreeAsync(d_rssi, st));
+    WH_HIP(hipFreeAsync(d_acc, st));
     return WH_OK;
 }

@@ -15,7 +15,8 @@ fallback: without the built library (or without a GPU) the operators raise.
 from ._lib import LIB_PATH, lib  # noqa: F401  (raises ImportError if the .so is missing)
 from .channelizer import PolyphaseChannelizer, ChannelCalculator  # noqa: F401
 from .fft_backend import HipFFTBackend, FFTResult, FFTBackend, is_available, register_with  # noqa: F401
-from .channel_ops import ChannelBank, ChannelConfig, process_channel_dsp_stateless  # noqa: F401
+from .channel_ops import (ChannelBank, ChannelConfig, process_channel_dsp_stateless,  # noqa: F401
+                          update_signal_metrics)
 from .wire import pack_iq16, unpack_iq16, pack_pcm16  # noqa: F401
 from .c4fm import C4FMBank, C4FMDemodulator, c4fm_demod_simple  # noqa: F401
 from .cqpsk import CQPSKBank, CQPSKDemodulator, GardnerBank, GardnerTED  # noqa: F401
@@ -23,6 +24,6 @@ from .trunking import TrunkingDDC, ScannerMeasure, decimation_plan  # noqa: F401
 
 __all__ = [
     "PolyphaseChannelizer", "ChannelCalculator", "HipFFTBackend", "FFTResult", "FFTBackend", "is_available",
-    "register_with", "ChannelBank", "ChannelConfig", "process_channel_dsp_stateless", "pack_iq16", "unpack_iq16",
+    "register_with", "ChannelBank", "ChannelConfig", "process_channel_dsp_stateless", "update_signal_metrics", "pack_iq16", "unpack_iq16",
     "pack_pcm16", "C4FMBank", "C4FMDemodulator", "c4fm_demod_simple", "CQPSKBank", "CQPSKDemodulator", "GardnerBank", "GardnerTED", "TrunkingDDC", "ScannerMeasure", "decimation_plan",
 ]

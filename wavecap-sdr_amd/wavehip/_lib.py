@@ -80,6 +80,8 @@ PROTOTYPES = {
     "wh_chanbank_run": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "wh_chanbank_workspace_bytes": (c_size_t, [c_void_p, c_size_t]),
     "wh_chanbank_destroy": (None, [c_void_p]),
+    "wh_channel_signal_metrics": (c_int, [c_void_p, c_int, c_size_t, c_int, C.POINTER(c_int), c_int, C.POINTER(c_float),
+                                          c_void_p]),
     "wh_pfb_create": (c_int, [C.POINTER(c_void_p), c_int, c_int, C.POINTER(c_double)]),
     "wh_pfb_hops": (c_size_t, [c_void_p, c_size_t]),
     "wh_pfb_run": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),

@@ -304,6 +304,38 @@ class ChannelBank:
         return out
 
 
+def update_signal_metrics(samples, sample_rate: int, offsets_hz, input_format: str = "cf32") -> list[dict[str, Any]]:
+    """Channel.update_signal_metrics (capture.py:749-798) for all channels of one chunk in one pass:
+    [{"rssi_db": float, "snr_db": float | None}] -- RSSI = 10 log10(mean |base|^2 + 1e-10); SNR from the
+    10th / 90th percentile magnitudes exactly as np.partition picks them.  (The reference throttles the SNR
+    part to every 10th call; here it costs one extra select pass, so it is always returned.)"""
+    torch = _lib.require_gpu()
+    if torch.is_tensor(samples):
+        d = samples
+        n = d.numel() // (2 if d.dtype == torch.int16 else 1)
+        fmt = 1 if d.dtype == torch.int16 else 0
+    else:
+        fmt = {"cf32": 0, "int16": 1}[input_format]
+        x = np.ascontiguousarray(samples, dtype=np.int16 if fmt else np.complex64)
+        n = x.shape[0] // (2 if fmt else 1)
+        d = torch.from_numpy(x).cuda()
+    offs = np.array([int(round(float(o))) if float(o) != 0.0 else 0 for o in offsets_hz], dtype=np.int32)
+    out = np.zeros((len(offs), 3), dtype=np.float32)
+    _lib.check(_lib.lib.wh_channel_signal_metrics(d.data_ptr(), fmt, n, int(sample_rate), _lib.dptr(offs, "i32"),
+                                                  len(offs), _lib.dptr(out, "f32"), _lib.stream_ptr(torch)),
+               "wh_channel_signal_metrics")
+    res = []
+    k_noise, k_signal = n // 10, n - n // 10 - 1
+    for k in range(len(offs)):
+        m: dict[str, Any] = {"rssi_db": float(out[k, 0]), "snr_db": None}
+        if k_noise > 0 and k_signal > k_noise:
+            noise_power, signal_power = np.float32(out[k, 1]) ** 2, np.float32(out[k, 2]) ** 2
+            if noise_power > 1e-10:
+                m["snr_db"] = float(10.0 * np.log10(signal_power / noise_power))
+        res.append(m)
+    return res
+
+
 _bank_cache: dict[tuple, ChannelBank] = {}
 
 
