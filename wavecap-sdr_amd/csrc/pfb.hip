@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
             wA[i] = wA[i + GH];
             wB[i] = wB[i + GH];
         }
-        if (g + 1 < g1) {
+        if (g + 1 < g1) {   // (a second prefetch stage, one more group ahead, measured 1 % slower)
             const long long xn = (h + GH + 1) * FHOP + t;
 #pragma unroll
             for (int i = 0; i < GH; ++i) {
