@@ -1,0 +1,104 @@
+"""BASELINE.json full-size configurations, checked through size-independent properties (the oracle
+would take minutes to hours at these sizes) plus oracle spot checks on slices."""
+
+import numpy as np
+import pytest
+
+import signals as S
+from conftest import peak_rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config3_pfb_full_size_2p28():
+    """1024-channel filterbank on 2^28 samples: every row of a spot-checked window equals the oracle on
+    that window's input (hop h depends only on samples (h-8)*512 .. h*512+1023), and a centred tone
+    lands in its channel over the whole 524 287-hop output."""
+    import torch
+    import wavehip
+    from oracle import ref_np as O
+
+    n = 1 << 28
+    ch = wavehip.PolyphaseChannelizer(10_000_000, 9765)
+    g = torch.Generator(device="cuda").manual_seed(33)
+    x = torch.view_as_complex(torch.randn(n, 2, device="cuda", generator=g).mul_(0.5))
+    y = ch.process_device(x)
+    assert y.shape == (524287, 1024)
+    ref = O.PolyphaseChannelizer(10_000_000, 9765)
+    for h0 in (0, 1000, 262144, 524287 - 40):          # first hops (zero history), middle, the ragged tail
+        lo = max(0, h0 - 8) * 512
+        seg = x[lo: (h0 + 40) * 512 + 1024].cpu().numpy()
+        ref.reset()
+        r = ref.process(seg)
+        off = h0 - lo // 512
+        want = r[off: off + 40]
+        got = y[h0: h0 + len(want)].cpu().numpy()
+        if h0 == 0:
+            assert peak_rel_err(got, want) <= 1e-5
+        else:   # rows with a full 8-block history inside the segment
+            assert peak_rel_err(got[:len(want)], want) <= 1e-5
+    del y
+    k = 300
+    t = torch.arange(n, device="cuda", dtype=torch.int64)
+    ph = (2 * np.pi / 1024) * ((t * k) % 1024).to(torch.float64)
+    tone = torch.complex(torch.cos(ph), torch.sin(ph)).to(torch.complex64)
+    del t, ph
+    ch.reset()
+    yt = ch.process_device(tone)
+    p = (yt[16:].abs() ** 2).mean(0)
+    assert int(p.argmax()) == k and p[k].item() > 0.75 * p.sum().item()
+
+
+def test_config2_nbfm_10s_int16_bank():
+    """32 NBFM channels, 10 s of a 2.4 MS/s int16 stream in ONE launch (200 chunks): chunks are
+    independent (stateless operator), so chunk c of the batch == that chunk run alone; spot-check the
+    oracle on two (chunk, channel) pairs."""
+    import torch
+    import wavehip
+    from oracle import ref_np as O
+
+    fs, n, K, chunks = 2_400_000, 120_000, 32, 200
+    offs = S.nbfm_bank_offsets(K)
+    cfgs = [wavehip.ChannelConfig(mode="nbfm", offset_hz=o, enable_deemphasis=False) for o in offs]
+    bank = wavehip.ChannelBank(fs, n, cfgs, input_format="int16")
+    parts = [S.pack_iq16_np(S.nbfm_bank_c64(n, fs, seed=900 + c % 4, start=(c % 4) * n)) for c in range(4)]
+    i16 = np.concatenate([parts[c % 4] for c in range(chunks)])
+    a, m = bank.process_device(torch.from_numpy(i16).cuda(), chunks)
+    assert a.shape == (chunks, K, 2400) and bool(torch.isfinite(a).all()) and float(a.abs().max()) <= 0.95 + 1e-6
+    for c in (0, 77, 199):
+        a1, m1 = bank.process_device(torch.from_numpy(parts[c % 4]).cuda(), 1)
+        assert torch.equal(a1[0], a[c]) and torch.allclose(m1[0], m[c], atol=1e-5)
+    z = O.unpack_iq16(parts[199 % 4])
+    for k in (3, 28):
+        ref, met = O.process_channel_nbfm(z, fs, offs[k])
+        assert peak_rel_err(a[199, k].cpu().numpy(), ref) <= 1e-5
+        assert abs(float(m[199, k, 0]) - met["rssi_db"]) <= 2e-4
+
+
+def test_config4_c4fm_64ch_10s_bit_exact():
+    """64 P25 C4FM channels, 10 s at 48 kHz in 100 ms calls: dibits and soft symbols of four channels
+    bit-identical to the C oracle; every channel produces the nominal symbol count and locks."""
+    import torch
+    import wavehip
+    from oracle.c4fm_c import C4FMDemodulatorRef
+
+    fs, C, call, n = 48000, 64, 4800, 480000
+    base, _ = S.c4fm_iq(n, fs, 1000, snr_db=20.0, freq_offset_hz=137.0)
+    x = torch.from_numpy(base).cuda()
+    ph = torch.exp(2j * np.pi * torch.arange(C, device="cuda")[:, None] * 3.0
+                   * torch.arange(n, device="cuda")[None, :] / fs).to(torch.complex64)
+    xs = (x[None, :] * ph).contiguous()
+    bank = wavehip.C4FMBank(C, fs, max_samples_per_call=call)
+    check = (0, 21, 42, 63)
+    refs = {c: C4FMDemodulatorRef(sample_rate=fs, atan_mode=1) for c in check}
+    host = {c: xs[c].cpu().numpy() for c in check}
+    total = torch.zeros(C, dtype=torch.int64, device="cuda")
+    for s in range(0, n, call):
+        d, sf, cnt = bank.demodulate_device(xs[:, s:s + call])
+        total += cnt
+        dc, sc, cc = d.cpu().numpy(), sf.cpu().numpy(), cnt.cpu().numpy()
+        for c in check:
+            rd, rs = refs[c].demodulate(host[c][s:s + call])
+            assert np.array_equal(dc[c, :cc[c]], rd) and np.array_equal(sc[c, :cc[c]], rs), (c, s)
+    assert int(total.min()) >= 47990 and int(total.max()) <= 48010
+    assert all(r.state()["sync_count"] > 100 for r in refs.values())
