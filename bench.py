@@ -203,9 +203,9 @@ def main() -> None:
         ch.process_device(x, out)
         ch.channel_stats_device(out[hops - scan:], stats)
         if reducer is not None:
-            merged = reducer.wait()          # scan i-1 (stream-ordered wait, no host sync)
+            gathered = reducer.wait(merge=False)   # scan i-1 (stream-ordered wait, no host sync)
             reducer.submit(stats)
-            return merged
+            return gathered
         if world > 1:
             return reduce_channel_stats(stats.cpu())
         return stats
@@ -228,7 +228,8 @@ def main() -> None:
         step()
         kernel_ms.append(ch.last_kernel_ms())      # waits for that step's fused kernel only
     if reducer is not None:
-        reducer.wait()                      # the last scan's exchange is inside the timed region
+        last = reducer.wait(merge=True)     # the last scan's exchange + merge are inside the timed region
+        assert last is not None and last.shape == (M, 5)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -46,15 +46,21 @@ class AsyncStatsReducer:
         work = dist.all_gather_into_tensor(out, stats.contiguous(), group=self.group, async_op=True)
         self._pending = (work, out.view((world,) + tuple(stats.shape)))
 
-    def wait(self):
-        """Block the CURRENT stream on the pending collective (no host sync) and return the merge."""
-        import torch
-
+    def wait(self, merge: bool = True):
+        """Block the CURRENT stream on the pending collective (no host sync).  Returns the merged
+        [M, 5] view, or with merge=False the raw gathered [world, M, 5] block (merge it later with
+        `merge_gathered`, e.g. once per scan interval instead of once per pass)."""
         if self._pending is None:
             return None
         work, out = self._pending
         self._pending = None
         work.wait()
+        return self.merge_gathered(out) if merge else out
+
+    @staticmethod
+    def merge_gathered(out):
+        import torch
+
         return torch.cat([out[:, :, 0:3].sum(0), out[:, :, 3].min(0).values[:, None],
                           out[:, :, 4].max(0).values[:, None]], dim=1)
 
