@@ -43,6 +43,9 @@ int wh_unpack_i16_cf32(const int16_t *d_in, float *d_out, size_t n_complex, void
 int wh_pack_cf32_i16(const float *d_in, int16_t *d_out, size_t n_complex, void *stream);
 int wh_pack_f32_pcm16(const float *d_in, int16_t *d_out, size_t n, void *stream);
 
+/* pack_f32, capture.py:134-144: clip to [-1, 1] (the bytes are the float32 array itself) */
+int wh_clip_f32(const float *d_in, float *d_out, size_t n, void *stream);
+
 /* ---- A2: stateless NCO mix, capture.py:166-193 freq_shift -------------------------
  * phase[n] = f32(-2 pi off/fs) * f32(n) (float32 product), restarted every call.     */
 int wh_nco_mix(const float *d_iq, float *d_out, size_t n, int offset_hz, int sample_rate,
@@ -205,6 +208,13 @@ int wh_c4fm_bank_run(wh_c4fm_bank *b, const float *d_iq, size_t n, size_t iq_str
                      uint8_t *d_dibits, float *d_soft, size_t out_cap, int32_t *d_counts, void *stream);
 int wh_c4fm_bank_reset(wh_c4fm_bank *b, void *stream);
 void wh_c4fm_bank_destroy(wh_c4fm_bank *b);
+
+/* ---- N2: P25P1SoftSyncDetector.process_batch, decoders/p25_framer.py:124-231 -----------------
+ * d_soft float32 [C][stride] (n symbols per channel) -> d_scores float32 [C][stride]: correlation of the
+ * 24 most recent symbols with the frame sync 0x5575F5FF77FF (+-3), one score per symbol; d_hist_in /
+ * d_hist_out float32 [C][24] carry the last 24 symbols (oldest first) between calls (distinct buffers). */
+int wh_sync_correlate(const float *d_soft, size_t n, size_t stride, int n_channels, const float *d_hist_in,
+                      float *d_hist_out, float *d_scores, void *stream);
 
 /* ---- A12: P25 Phase-2 CQPSK bank, dsp/p25/cqpsk.py:199-350 + dsp/p25/symbol_timing.py -------
  * RRC matched filter (h_rrc float32 = design_rrc_filter_phase2, h_zi = lfilter_zi(rrc, 1.0)),

@@ -402,7 +402,30 @@ def gen_cqpsk():
     save("cqpsk", **out)
 
 
-ALL = dict(cqpsk=gen_cqpsk, trunk=gen_trunk, a1=gen_a1, a2=gen_a2, a3=gen_a3, a6=gen_a6, chain=gen_chain, a7=gen_a7, a8=gen_a8, c4fm=gen_c4fm)
+def gen_framer():
+    """N2: P25P1SoftSyncDetector.process_batch (decoders/p25_framer.py:192-231); N4: pack_f32 (capture.py:134-144)."""
+    from wavecapsdr.decoders.p25_framer import P25P1SoftSyncDetector
+
+    rng = np.random.default_rng(1700)
+    dib = S.c4fm_frames_dibits(2000, 1701, frame_len=360)
+    soft = (np.array([1.0, 3.0, -1.0, -3.0])[dib] + 0.3 * rng.standard_normal(dib.size)).astype(np.float32)
+    det = P25P1SoftSyncDetector()
+    lens = [700, 5, 1, 0, 23, 24, 25, 1222]
+    pos, outs = 0, []
+    for n in lens:
+        outs.append(det.process_batch(soft[pos:pos + n]))
+        pos += n
+    assert pos == soft.size
+    det1 = P25P1SoftSyncDetector()
+    single = np.array([det1.process(float(v)) for v in soft[:64]], dtype=np.float32)
+    vals = np.concatenate([np.array([1.0, -1.0, 1.5, -1.5, 0.0, -0.0, np.nan, np.inf, -np.inf, 1.0000001], dtype=np.float32),
+                           rng.uniform(-1.3, 1.3, 2038).astype(np.float32)])
+    f32 = np.frombuffer(rc.pack_f32(vals.copy()), dtype=np.float32)
+    save("framer", soft=soft, lens=np.array(lens, dtype=np.int64), scores=np.concatenate(outs), single=single,
+         pattern=det.SYNC_PATTERN_SYMBOLS, f32_in=vals, f32_out=f32)
+
+
+ALL = dict(framer=gen_framer, cqpsk=gen_cqpsk, trunk=gen_trunk, a1=gen_a1, a2=gen_a2, a3=gen_a3, a6=gen_a6, chain=gen_chain, a7=gen_a7, a8=gen_a8, c4fm=gen_c4fm)
 
 if __name__ == "__main__":
     import logging

@@ -669,3 +669,37 @@ def scanner_measure(iq: np.ndarray, sample_rate: int, channel_offsets_hz, sync_c
             m["sync_detected"] = bool(m["snr_db"] >= 8.0 and abs(m["sync_correlation"]) > 0.6)
         res.append(m)
     return res
+
+
+# ----------------------------------------------------------------------------------------------
+# N2: P25P1SoftSyncDetector (reference decoders/p25_framer.py:124-231); N4: pack_f32 (capture.py:134-144)
+# ----------------------------------------------------------------------------------------------
+
+P25_SYNC_SYMBOLS = np.array([3.0 if ((0x5575F5FF77FF >> ((23 - i) * 2)) & 3) == 1 else -3.0 for i in range(24)],
+                            dtype=np.float32)
+
+
+class SoftSyncDetector:
+    """State = the last 24 soft symbols (zeros at reset); score i = <pattern, symbols i-23..i>."""
+
+    def __init__(self):
+        self.hist = np.zeros(24, dtype=np.float32)
+
+    def reset(self):
+        self.hist[:] = 0.0
+
+    def process_batch(self, soft: np.ndarray) -> np.ndarray:
+        soft = np.asarray(soft, dtype=np.float32)
+        n = soft.size
+        if n == 0:
+            return np.array([], dtype=np.float32)
+        ext = np.concatenate([self.hist, soft])
+        scores = np.correlate(ext, P25_SYNC_SYMBOLS, mode="valid")[-n:]
+        self.hist = ext[-24:].copy()
+        return scores.astype(np.float32)
+
+
+def pack_f32(samples: np.ndarray) -> bytes:
+    if samples.size == 0:
+        return b""
+    return np.clip(samples.astype(np.float32), -1.0, 1.0).tobytes()

@@ -431,3 +431,43 @@ def test_a13_scanner_measure(wh, golden, O):
     assert [float(m["sync_detected"]) for m in res2] == list(g["scan2_meas"][:, 4])
     for a, b in zip(res2, ref2):
         assert abs(a["sync_correlation"] - b["sync_correlation"]) <= 1e-6
+
+
+def test_n2_soft_sync_detector(wh, golden, O):
+    """P25P1SoftSyncDetector.process_batch on ragged calls (incl. n < 24, n == 0) vs reference scores;
+    tolerance 1e-5 of peak (24-term f32 dot product, summation order differs from np.correlate)."""
+    g = golden("framer")
+    det = wh.P25P1SoftSyncDetector()
+    assert np.array_equal(det.SYNC_PATTERN_SYMBOLS, g["pattern"])
+    pos, outs = 0, []
+    for n in g["lens"]:
+        outs.append(det.process_batch(g["soft"][pos:pos + int(n)]))
+        pos += int(n)
+    got = np.concatenate(outs)
+    assert got.dtype == np.float32 and got.shape == g["scores"].shape
+    assert peak_rel_err(got, g["scores"]) <= 1e-5
+    # the sync positions score 24 * 9 = 216 nominal: same argmax set as the reference
+    assert np.array_equal(np.nonzero(got > 150)[0], np.nonzero(g["scores"] > 150)[0])
+    det.reset()
+    single = np.array([det.process(float(v)) for v in g["soft"][:64]], dtype=np.float32)
+    assert peak_rel_err(single, g["single"]) <= 1e-5
+
+
+def test_n2_soft_sync_bank_matches_per_channel(wh, O):
+    import torch
+    rng = np.random.default_rng(1710)
+    C, n = 37, 5000
+    soft = rng.uniform(-4, 4, (C, 2 * n)).astype(np.float32)
+    bank = wh.SoftSyncBank(C)
+    a = bank.process_device(torch.from_numpy(soft[:, :n].copy()).cuda()).cpu().numpy()
+    b = bank.process_device(torch.from_numpy(soft[:, n:].copy()).cuda()).cpu().numpy()
+    for c in (0, 17, C - 1):
+        ref = O.SoftSyncDetector()
+        want = np.concatenate([ref.process_batch(soft[c, :n]), ref.process_batch(soft[c, n:])])
+        assert peak_rel_err(np.concatenate([a[c], b[c]]), want) <= 1e-5
+
+
+def test_n4_pack_f32(wh, golden):
+    g = golden("framer")
+    assert wh.pack_f32(g["f32_in"]) == g["f32_out"].tobytes()
+    assert wh.pack_f32(np.array([], dtype=np.float32)) == b""

@@ -1,0 +1,75 @@
+// Small "next" rows:
+//   N2  P25P1SoftSyncDetector.process_batch (reference decoders/p25_framer.py:124-231): sliding 24-tap
+//       correlation of soft symbols with the frame-sync pattern, one score per symbol, state = the last
+//       24 symbols; banked over channels.
+//   N4  pack_f32 (reference capture.py:134-144): clip to [-1, 1] before the float32 wire format.
+#include "wh_common.h"
+
+using namespace wh;
+
+namespace {
+
+__device__ __forceinline__ float sync_sym(int i) {
+    return ((0x5575F5FF77FFULL >> ((23 - i) * 2)) & 3ULL) == 1ULL ? 3.0f : -3.0f;
+}
+
+__global__ __launch_bounds__(256) void sync_corr_kernel(const float *soft, size_t stride, int n, const float *hist_in,
+                                                        float *scores) {
+    const int c = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float *s = soft + (size_t)c * stride;
+    const float *h = hist_in + (size_t)c * 24;
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 24; ++j) {
+        int k = i - 23 + j;                    // symbol index relative to this call
+        float v = k >= 0 ? s[k] : h[24 + k];   // history: the 24 symbols before the call, oldest first
+        acc = fmaf(sync_sym(j), v, acc);
+    }
+    scores[(size_t)c * stride + i] = acc;
+}
+
+__global__ void sync_hist_kernel(const float *soft, size_t stride, int n, const float *hist_in, float *hist_out, int C) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= C * 24) return;
+    int c = idx / 24, j = idx % 24;
+    int k = n - 24 + j;
+    hist_out[idx] = k >= 0 ? soft[(size_t)c * stride + k] : hist_in[c * 24 + 24 + k];
+}
+
+__global__ void clip_kernel(const float *in, float *out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t st = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += st) {
+        float v = in[i];
+        out[i] = v != v ? v : fminf(fmaxf(v, -1.0f), 1.0f);   // np.clip keeps NaN
+    }
+}
+
+}  // namespace
+
+extern "C" int wh_sync_correlate(const float *d_soft, size_t n, size_t stride, int n_channels, const float *d_hist_in,
+                                 float *d_hist_out, float *d_scores, void *stream) {
+    if (n == 0) return WH_OK;
+    if (!d_soft || !d_hist_in || !d_hist_out || !d_scores || n_channels < 1 || n_channels > 65535 || stride < n ||
+        n > 0x7fffffff || d_hist_in == d_hist_out)
+        return set_err(WH_E_ARG, "wh_sync_correlate: bad arguments");
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(sync_corr_kernel, dim3((unsigned)((n + 255) / 256), n_channels), dim3(256), 0, st, d_soft, stride,
+                       (int)n, d_hist_in, d_scores);
+    WH_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sync_hist_kernel, dim3((n_channels * 24 + 255) / 256), dim3(256), 0, st, d_soft, stride, (int)n,
+                       d_hist_in, d_hist_out, n_channels);
+    WH_LAUNCH_CHECK();
+    return WH_OK;
+}
+
+extern "C" int wh_clip_f32(const float *d_in, float *d_out, size_t n, void *stream) {
+    if (n == 0) return WH_OK;
+    if (!d_in || !d_out) return set_err(WH_E_ARG, "wh_clip_f32: null buffer");
+    size_t g = (n + 255) / 256;
+    hipLaunchKernelGGL(clip_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, as_stream(stream), d_in, d_out, n);
+    WH_LAUNCH_CHECK();
+    return WH_OK;
+}

@@ -71,6 +71,8 @@ PROTOTYPES = {
     "wh_unpack_i16_cf32": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "wh_pack_cf32_i16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "wh_pack_f32_pcm16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wh_clip_f32": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wh_sync_correlate": (c_int, [c_void_p, c_size_t, c_size_t, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wh_nco_mix": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
     "wh_fm_discriminate": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "wh_resampler_create": (c_int, [C.POINTER(c_void_p), C.POINTER(c_double), c_int, c_int, c_int, c_int]),

@@ -2,6 +2,7 @@
 
 pack_iq16  <- capture.py:102-116 (returns bytes like the reference)
 pack_pcm16 <- capture.py:119-131
+pack_f32   <- capture.py:134-144
 unpack_iq16 <- cli.py:447-452 / harness.py:274
 """
 
@@ -45,3 +46,13 @@ def unpack_iq16(data) -> np.ndarray:
     _lib.check(_lib.lib.wh_unpack_i16_cf32(x.data_ptr(), out.data_ptr(), i16.size // 2, _lib.stream_ptr(torch)),
                "wh_unpack_i16_cf32")
     return out.cpu().numpy()
+
+
+def pack_f32(samples: np.ndarray) -> bytes:
+    if samples.size == 0:
+        return b""
+    torch = _lib.require_gpu()
+    x = torch.from_numpy(np.ascontiguousarray(samples, dtype=np.float32)).cuda()
+    out = torch.empty_like(x)
+    _lib.check(_lib.lib.wh_clip_f32(x.data_ptr(), out.data_ptr(), x.numel(), _lib.stream_ptr(torch)), "wh_clip_f32")
+    return out.cpu().numpy().tobytes()
