@@ -425,7 +425,71 @@ def gen_framer():
          pattern=det.SYNC_PATTERN_SYMBOLS, f32_in=vals, f32_out=f32)
 
 
-ALL = dict(framer=gen_framer, cqpsk=gen_cqpsk, trunk=gen_trunk, a1=gen_a1, a2=gen_a2, a3=gen_a3, a6=gen_a6, chain=gen_chain, a7=gen_a7, a8=gen_a8, c4fm=gen_c4fm)
+def gen_lsm():
+    """A12 (LSM): decoders/p25.py:190-669 CQPSKDemodulator on streamed, ragged calls.
+
+    The reference's Gardner loop never settles on a pi/4-DQPSK test signal (it emits ~4.7 % more symbols than
+    were sent: the clock slips continuously), which makes the symbol stream chaotic: a 1-ulp change (SVML vs
+    libm atan2f, the BLAS kernel behind np.convolve) first flips a dibit after ~4 600-12 000 symbols.  Each
+    case therefore restarts a fresh demodulator and stays ~2 500 symbols long.  Even so, on a scan of 20 seeds
+    about one case in three hit such a flip (the quantisation of mu to 1/128 steps, p25.py:341, is the
+    amplifier) in at least one of the oracle's two math flavours; the seeds below are ones where neither
+    flavour does -- the reference's own output is only reproducible across hosts in that sense."""
+    from wavecapsdr.decoders.p25 import CQPSKDemodulator as RefLSM
+
+    out = {}
+    cases = [
+        # fs, symbol_rate, n, seed, snr_db, freq_offset_hz, (chunk lo, hi), special
+        (48000, 4800, 25000, 1800, 25.0, 40.0, (900, 1700), ""),
+        (48000, 4800, 25000, 1801, 12.0, -60.0, (400, 2600), "tiny"),      # includes chunks < 63 samples
+        (19200, 4800, 10000, 1806, 25.0, -30.0, (300, 700), ""),
+        (48000, 6000, 20000, 1809, 20.0, 20.0, (900, 1700), "silence"),    # Phase-2 rate, zeros in the middle
+        (25000, 4800, 13000, 1804, 25.0, 10.0, (500, 900), ""),            # fractional sps 5.208
+        (144000, 4800, 60000, 1805, 25.0, 25.0, (2500, 5000), ""),         # round(sps)+4 >= 32: no Gardner, f64 clock
+    ]
+    for ci, (fs, sr, n, seed, snr, off, (lo, hi), special) in enumerate(cases):
+        sps_i = int(round(fs / sr))
+        x, _ = S.dqpsk_iq(n, sps_i * sr, seed, symbol_rate=sr, snr_db=snr, freq_offset_hz=off)
+        rng = np.random.default_rng(seed + 100)
+        lens = []
+        while sum(lens) < n:
+            lens.append(int(rng.integers(lo, hi)))
+            if special == "tiny" and len(lens) % 4 == 2:
+                lens.append(int(rng.integers(1, 62)))
+        lens[-1] -= sum(lens) - n
+        if lens[-1] <= 0:
+            lens.pop()
+            lens[-1] += n - sum(lens)
+        if special == "silence":
+            x = x.copy()
+            x[8000:9500] = 0
+        d = RefLSM(fs, sr)
+        pos, dib, st, cnt = 0, [], [], []
+        for ln in lens:
+            o = d.demodulate(x[pos:pos + ln])
+            pos += ln
+            dib.append(o)
+            cnt.append(len(o))
+            st.append([float(d._agc_gain), float(d._freq_offset), float(d._phase_acc), float(d._symbol_clock),
+                       float(np.real(d._prev_symbol)), float(np.imag(d._prev_symbol))])
+        assert pos == n
+        out[f"c{ci}_args"] = np.array([fs, sr, n, seed, snr, off], dtype=np.float64)
+        out[f"c{ci}_special"] = np.array(special)
+        out[f"c{ci}_sha"] = np.array(S.sha256(x))
+        out[f"c{ci}_lens"] = np.array(lens, dtype=np.int64)
+        out[f"c{ci}_dibits"] = np.concatenate(dib)
+        out[f"c{ci}_counts"] = np.array(cnt, dtype=np.int64)
+        out[f"c{ci}_phases"] = np.array(d._symbol_values, dtype=np.float32)
+        out[f"c{ci}_state"] = np.array(st, dtype=np.float64)
+        out[f"c{ci}_clock_is_f32"] = np.array(isinstance(d._symbol_clock, np.float32))
+        if ci == 0:
+            out["mmse"] = d._mmse_taps
+        out[f"c{ci}_lpf"] = d._baseband_taps
+    out["n_cases"] = np.array(len(cases))
+    save("lsm", **out)
+
+
+ALL = dict(lsm=gen_lsm, framer=gen_framer, cqpsk=gen_cqpsk, trunk=gen_trunk, a1=gen_a1, a2=gen_a2, a3=gen_a3, a6=gen_a6, chain=gen_chain, a7=gen_a7, a8=gen_a8, c4fm=gen_c4fm)
 
 if __name__ == "__main__":
     import logging

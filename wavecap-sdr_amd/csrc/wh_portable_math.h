@@ -99,3 +99,44 @@ WHM_FN void whm_sincos_phase(float phase, float *s_out, float *c_out) {
     *s_out = s;
     *c_out = c;
 }
+
+// sin/cos of a float64 angle, |x| < ~1e6 rad: Cody-Waite reduction by pi/2 (33-bit head, so k*head is
+// exact for |k| < 2^20), then the cephes double kernels on [-pi/4, pi/4] (error < 1 ulp).  Single rounded
+// float64 operations in a fixed order, so host and device agree bit for bit.
+WHM_FN void whm_sincos_f64(double x, double *s_out, double *c_out) {
+    double k = __builtin_rint(WHM_DMUL(x, 0.63661977236758134308));
+    double r = WHM_DSUB(WHM_DSUB(x, WHM_DMUL(k, 1.57079632673412561417e+00)), WHM_DMUL(k, 6.07710050650619224932e-11));
+    double z = WHM_DMUL(r, r);
+    double sp = 1.58962301576546568060e-10;
+    sp = WHM_DSUB(WHM_DMUL(sp, z), 2.50507477628578072866e-8);
+    sp = WHM_DADD(WHM_DMUL(sp, z), 2.75573136213857245213e-6);
+    sp = WHM_DSUB(WHM_DMUL(sp, z), 1.98412698295895385996e-4);
+    sp = WHM_DADD(WHM_DMUL(sp, z), 8.33333333332211858878e-3);
+    sp = WHM_DSUB(WHM_DMUL(sp, z), 1.66666666666666307295e-1);
+    double s = WHM_DADD(r, WHM_DMUL(WHM_DMUL(r, z), sp));
+    double cp = -1.13585365213876817300e-11;
+    cp = WHM_DADD(WHM_DMUL(cp, z), 2.08757008419747316778e-9);
+    cp = WHM_DSUB(WHM_DMUL(cp, z), 2.75573141792967388112e-7);
+    cp = WHM_DADD(WHM_DMUL(cp, z), 2.48015872888517045348e-5);
+    cp = WHM_DSUB(WHM_DMUL(cp, z), 1.38888888888730564116e-3);
+    cp = WHM_DADD(WHM_DMUL(cp, z), 4.16666666666665929218e-2);
+    double c = WHM_DADD(WHM_DSUB(1.0, WHM_DMUL(0.5, z)), WHM_DMUL(WHM_DMUL(z, z), cp));
+    long long q = (long long)k & 3;
+    double so, co;
+    if (q == 0) { so = s; co = c; }
+    else if (q == 1) { so = c; co = -s; }
+    else if (q == 2) { so = -s; co = -c; }
+    else { so = -c; co = s; }
+    *s_out = so;
+    *c_out = co;
+}
+
+// |re + j im| as glibc hypotf computes it: exact float64 squares, one rounded sum, correctly rounded sqrt.
+WHM_FN float whm_hypotf(float re, float im) {
+    double s = WHM_DADD(WHM_DMUL((double)re, (double)re), WHM_DMUL((double)im, (double)im));
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (float)__dsqrt_rn(s);
+#else
+    return (float)__builtin_sqrt(s);
+#endif
+}
