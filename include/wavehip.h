@@ -231,6 +231,24 @@ int wh_cqpsk_bank_run(wh_cqpsk_bank *b, const float *d_iq, size_t n, size_t iq_s
 int wh_cqpsk_bank_reset(wh_cqpsk_bank *b, void *stream);
 void wh_cqpsk_bank_destroy(wh_cqpsk_bank *b);
 
+/* ---- A12 (LSM): P25 Phase-1 CQPSK / linear simulcast demodulator, decoders/p25.py:190-669 -------------
+ * Per call and channel: block AGC (:436-455), NCO from the tracked frequency offset (:460-465), 63-tap
+ * 'same'-mode low-pass (:468-471; per call, zero-padded edges, float64 once the NCO runs), then the
+ * symbol-clock loop with 8-tap MMSE interpolation, pi/4-DQPSK slicer, frequency loop and Gardner timing
+ * error (:484-669), in the reference's NumPy-2 scalar types.  h_lpf float32[63] (:370-383), h_mmse
+ * float32[129*8] (:289-323).  run(): d_iq complex64 [C][iq_stride], n <= max_samples_per_call samples per
+ * channel = ONE reference demodulate() call -> d_dibits uint8 [C][cap] (cap >= n), d_phases (optional, may
+ * be NULL) float32 [C][cap] differential phase per symbol, d_counts int32 [C].  get_state(): h_out[7] =
+ * agc_gain, freq_offset, phase_acc, symbol_clock, prev_symbol re / im, clock_is_float32.            */
+typedef struct wh_lsm_bank wh_lsm_bank;
+int wh_lsm_bank_create(wh_lsm_bank **out, int n_channels, double samples_per_symbol, const float *h_lpf,
+                       const float *h_mmse, int max_samples_per_call);
+int wh_lsm_bank_run(wh_lsm_bank *b, const float *d_iq, size_t n, size_t iq_stride, uint8_t *d_dibits, float *d_phases,
+                    size_t cap, int32_t *d_counts, void *stream);
+int wh_lsm_bank_reset(wh_lsm_bank *b, void *stream);
+int wh_lsm_bank_get_state(wh_lsm_bank *b, int channel, double *h_out, void *stream);
+void wh_lsm_bank_destroy(wh_lsm_bank *b);
+
 /* Gardner timing error detector bank, dsp/p25/symbol_timing.py:60-211 (GardnerTED.process_block):
  * d_x float32 [C][stride] -> d_symbols / d_errors float64 [C][cap], d_counts int32 [C].       */
 typedef struct wh_gardner_bank wh_gardner_bank;
