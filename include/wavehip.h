@@ -46,6 +46,10 @@ int wh_pack_f32_pcm16(const float *d_in, int16_t *d_out, size_t n, void *stream)
 /* pack_f32, capture.py:134-144: clip to [-1, 1] (the bytes are the float32 array itself) */
 int wh_clip_f32(const float *d_in, float *d_out, size_t n, void *stream);
 
+/* validate_audio_samples (validation.py:41-52) + signal power (capture.py:436-437) of a float32 device
+ * buffer: h_out[3] = {mean(x^2), max |x|, 1 if all finite else 0}.  Synchronous.                      */
+int wh_audio_stats(const float *d_x, size_t n, float *h_out, void *stream);
+
 /* ---- A2: stateless NCO mix, capture.py:166-193 freq_shift -------------------------
  * phase[n] = f32(-2 pi off/fs) * f32(n) (float32 product), restarted every call.     */
 int wh_nco_mix(const float *d_iq, float *d_out, size_t n, int offset_hz, int sample_rate,
@@ -75,7 +79,9 @@ void wh_resampler_destroy(wh_resampler *r);
  * Chain: NCO mix (capture.py:166-193) -> demod front -> IIR stages -> [AGC] -> resample_poly ->
  * post.  The host designs every filter exactly as the reference does and passes coefficients:
  *   demod 0 FM discriminator (dsp/fm.py:65-97), 1 AM envelope (dsp/am.py:103),
- *         2 SSB product detector with float64-phase BFO at bfo_hz (dsp/am.py:23-42, 200-210);
+ *         2 SSB product detector with float64-phase BFO at bfo_hz (dsp/am.py:23-42, 200-210),
+ *         3 / 4 / 5 synchronous AM dsb / usb / lsb: carrier-recovery PLL, fresh per chunk, float64
+ *         (dsp/sam.py:73-122, 219-232) with loop coefficients pll_alpha / pll_beta (dsp/sam.py:55-66);
  *   stages: lfilter(b, a) sections in application order, float32 (de-emphasis, dsp/fm.py:101-126)
  *         or float64 (Butterworth / notch, dsp/filters.py:86-264, dsp/fm.py:129-181), zero state
  *         per chunk, output of each rounded to float32;
@@ -95,7 +101,7 @@ typedef struct wh_chanbank_cfg {
     int n_channels;
     const int *h_offsets_hz;/* round(offset_hz) per channel; 0 = no mix (capture.py:328) */
     int input_format;       /* 0 = complex64, 1 = int16 IQ */
-    int demod;              /* 0 FM, 1 AM, 2 SSB */
+    int demod;              /* 0 FM, 1 AM, 2 SSB, 3/4/5 SAM dsb/usb/lsb */
     double bfo_hz;          /* demod 2: +bfo (USB) / -bfo (LSB) */
     int n_stages;           /* <= 8 */
     const wh_iir_stage *h_stages;
@@ -106,6 +112,7 @@ typedef struct wh_chanbank_cfg {
     const double *h_taps;   /* resample_poly taps (see wh_resampler_create); NULL when ntaps == 0 */
     int ntaps, up, down, d0;
     int n_out;              /* ceil(N*up/down), or N when ntaps == 0 */
+    double pll_alpha, pll_beta; /* demod 3..5: 2*damping*omega_n/fs, omega_n^2/fs^2 */
 } wh_chanbank_cfg;
 int wh_chanbank_create(wh_chanbank **out, const wh_chanbank_cfg *cfg);
 int wh_chanbank_run(wh_chanbank *b, const void *d_in, size_t n_chunks, float *d_audio, float *d_metrics,

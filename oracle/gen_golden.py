@@ -189,6 +189,57 @@ def gen_chain():
     save("chain_analog", **out)
 
 
+def gen_rawdig():
+    """capture.py:415-430: the "raw" and digital-voice branches of _process_channel_dsp_stateless."""
+    out = {}
+    fs, n = 2400000, 4096
+    iq = S.nbfm_bank_c64(n, fs, seed=550)
+    out["sha"] = np.array(S.sha256(iq))
+    out["args"] = np.array([fs, n, 550], dtype=np.int64)
+    for ci, off in enumerate([0.0, 175000.0]):
+        rc._get_freq_shift_exp.cache_clear()
+        audio, met = rc._process_channel_dsp_stateless(iq, fs, rc.ChannelConfig(id="r", capture_id="c", mode="raw", offset_hz=off))
+        out[f"raw{ci}_audio"] = audio
+        out[f"raw{ci}_met"] = np.array([met["rssi_db"], met["signal_power_db"]])
+        rc._get_freq_shift_exp.cache_clear()
+        audio, met = rc._process_channel_dsp_stateless(iq, fs, rc.ChannelConfig(id="d", capture_id="c", mode="p25", offset_hz=off))
+        assert audio is None
+        out[f"dig{ci}_met"] = np.array([met["rssi_db"], met["signal_power_db"]])
+    out["offs"] = np.array([0.0, 175000.0])
+    # raw IQ above the audio clip limit fails validate_audio_samples: (None, {rssi_db})
+    audio, met = rc._process_channel_dsp_stateless((iq * 40).astype(np.complex64), fs,
+                                                   rc.ChannelConfig(id="r", capture_id="c", mode="raw", offset_hz=0.0))
+    assert audio is None and "signal_power_db" not in met
+    out["loud_rssi"] = np.array(met["rssi_db"])
+    save("chain_rawdig", **out)
+
+
+def gen_sam():
+    """A14: "sam" mode of _process_channel_dsp_stateless (capture.py:386-399 -> dsp/sam.py:132-269), at rates
+    where the order-5 ba-form Butterworths are well conditioned (see gen_chain)."""
+    out = {}
+    cases = [
+        # tag, fs, n, seed, carrier_hz (signal), offset_hz (channel), kwargs
+        ("dsb48", 48000, 4800, 560, 4815.0, 4800.0, dict(enable_agc=True)),                    # 15 Hz residual carrier
+        ("usb48", 48000, 4800, 561, 4790.0, 4800.0, dict(enable_agc=True, sam_sideband="usb")),
+        ("lsb32", 32000, 3200, 562, 3200.0, 3200.0, dict(enable_agc=False, sam_sideband="lsb", audio_rate=16000)),
+        ("dsb96", 96000, 9600, 563, 30.0, 0.0, dict(enable_agc=True, enable_am_highpass=False, sam_pll_bandwidth_hz=100.0)),
+    ]
+    for tag, fs, n, seed, car, off, kw in cases:
+        iq = S.am_tone_c64(n, fs, seed=seed, carrier_hz=car, depth=0.7)
+        cfg = rc.ChannelConfig(id="s", capture_id="c", mode="sam", offset_hz=off, **kw)
+        rc._get_freq_shift_exp.cache_clear()
+        audio, met = rc._process_channel_dsp_stateless(iq, fs, cfg)
+        assert audio is not None, tag
+        out[f"{tag}_sha"] = np.array(S.sha256(iq))
+        out[f"{tag}_audio"] = audio
+        out[f"{tag}_met"] = np.array([met["rssi_db"], met["signal_power_db"]])
+        out[f"{tag}_args"] = np.array([fs, n, seed, car, off], dtype=np.float64)
+        out[f"{tag}_kw"] = np.array(repr(kw))
+    out["tags"] = np.array([c[0] for c in cases])
+    save("chain_sam", **out)
+
+
 def gen_a7():
     out = {}
     cases = [(1_000_000, 25000, 40, 701), (8_000_000, 25000, 320, 702), (10_000_000, 9765, 1024, 703)]
@@ -489,7 +540,7 @@ def gen_lsm():
     save("lsm", **out)
 
 
-ALL = dict(lsm=gen_lsm, framer=gen_framer, cqpsk=gen_cqpsk, trunk=gen_trunk, a1=gen_a1, a2=gen_a2, a3=gen_a3, a6=gen_a6, chain=gen_chain, a7=gen_a7, a8=gen_a8, c4fm=gen_c4fm)
+ALL = dict(sam=gen_sam, rawdig=gen_rawdig, lsm=gen_lsm, framer=gen_framer, cqpsk=gen_cqpsk, trunk=gen_trunk, a1=gen_a1, a2=gen_a2, a3=gen_a3, a6=gen_a6, chain=gen_chain, a7=gen_a7, a8=gen_a8, c4fm=gen_c4fm)
 
 if __name__ == "__main__":
     import logging

@@ -396,6 +396,47 @@ def ssb_demod(iq: np.ndarray, sample_rate: int, audio_rate: int = 48_000, mode: 
     return audio
 
 
+def sam_demod(iq: np.ndarray, sample_rate: int, audio_rate: int = 48_000, sideband: str = "dsb",
+              pll_bandwidth: float = 50.0, enable_agc: bool = True, enable_highpass: bool = True,
+              highpass_hz: float = 100.0, enable_lowpass: bool = True, lowpass_hz: float = 5000.0,
+              agc_target_db: float = -20.0) -> np.ndarray:
+    """dsp/sam.py:132-269 as reached through sam_demod_simple (fresh PLL per call, no notch / blanker).
+    PLL (:73-122): float64 phase / integrator, LO exp(-1j phase) in complex128, outputs stored as float32."""
+    fs = float(sample_rate)
+    omega_n = 2 * np.pi * pll_bandwidth
+    alpha, beta = 2 * 0.707 * omega_n / fs, (omega_n ** 2) / (fs ** 2)
+    n = iq.shape[0]
+    ci = np.zeros(n, dtype=np.float32)
+    cq = np.zeros(n, dtype=np.float32)
+    x = iq.astype(np.complex128)
+    phase = integ = 0.0
+    import math
+    for i in range(n):
+        lr, li = math.cos(phase), -math.sin(phase)
+        xr, xi = x[i].real, x[i].imag
+        mr, mi = xr * lr - xi * li, xr * li + xi * lr
+        ci[i], cq[i] = mr, mi
+        pe = math.atan2(mi, abs(mr) + 1e-10)
+        integ += beta * pe
+        phase += alpha * pe + integ
+        if phase > math.pi:
+            phase -= 2 * math.pi
+        elif phase < -math.pi:
+            phase += 2 * math.pi
+    sb = sideband.lower()
+    audio = ci + cq if sb == "usb" else (ci - cq if sb == "lsb" else ci)
+    if enable_highpass and highpass_hz > 0:
+        audio = butter_filter(audio, sample_rate, "high", highpass_hz)
+    if enable_lowpass and lowpass_hz > 0:
+        audio = butter_filter(audio, sample_rate, "low", lowpass_hz)
+    if enable_agc:
+        audio = apply_agc(audio, sample_rate, target_db=agc_target_db)
+    audio = resample_poly(audio, sample_rate, audio_rate)
+    if not enable_agc:
+        audio = soft_clip_agc(audio)
+    return audio
+
+
 def fm_demod_filtered(iq: np.ndarray, sample_rate: int, audio_rate: int = 48_000, *, deemphasis_tau=None,
                       mpx_cutoff_hz=None, highpass_hz=None, lowpass_hz=None, notch_frequencies=None) -> np.ndarray:
     """dsp/fm.py:228-406 with any subset of the optional IIR stages, in the reference's order:
@@ -428,6 +469,26 @@ def process_channel(samples: np.ndarray, sample_rate: int, offset_hz: float, dem
     if not np.isfinite(audio).all() or float(np.max(np.abs(audio))) > 1.2:
         return None, metrics
     metrics["signal_power_db"] = channel_metrics_db(audio)
+    return audio, metrics
+
+
+def process_channel_raw_or_digital(samples: np.ndarray, sample_rate: int, offset_hz: float, mode: str):
+    """capture.py:415-430: "raw" = shifted IQ interleaved as float32 (validated like audio); the digital voice
+    modes return no audio and signal_power_db = power of the shifted IQ."""
+    metrics = {}
+    if samples.size == 0 or not np.isfinite(samples).all():
+        return None, metrics
+    base = samples if offset_hz == 0.0 else freq_shift(samples, offset_hz, sample_rate)
+    metrics["rssi_db"] = float(10.0 * np.log10(np.mean(np.abs(base) ** 2) + 1e-10))
+    if mode != "raw":
+        metrics["signal_power_db"] = metrics["rssi_db"]
+        return None, metrics
+    audio = np.empty(base.size * 2, dtype=np.float32)
+    audio[0::2] = base.real
+    audio[1::2] = base.imag
+    if not np.isfinite(audio).all() or float(np.max(np.abs(audio))) > 1.2:
+        return None, metrics
+    metrics["signal_power_db"] = float(10.0 * np.log10(np.mean(audio ** 2) + 1e-10))
     return audio, metrics
 
 

@@ -151,7 +151,7 @@ def test_chain_nbfm_single_channel_dropin(wh, golden):
     bad[100] = np.nan
     assert wh.process_channel_dsp_stateless(bad, fs, _nbfm_cfg(wh, offs[13])) == (None, {})
     with pytest.raises(NotImplementedError):
-        wh.process_channel_dsp_stateless(z, fs, wh.ChannelConfig(mode="sam"))
+        wh.process_channel_dsp_stateless(z, fs, wh.ChannelConfig(mode="nbfm", enable_noise_reduction=True))
 
 
 def test_chain_nbfm_multichunk_matches_single(wh):
@@ -471,3 +471,43 @@ def test_n4_pack_f32(wh, golden):
     g = golden("framer")
     assert wh.pack_f32(g["f32_in"]) == g["f32_out"].tobytes()
     assert wh.pack_f32(np.array([], dtype=np.float32)) == b""
+
+
+def test_chain_raw_and_digital_modes(wh, golden):
+    """capture.py:415-430 branches of the operator: "raw" (shifted IQ interleaved, validated like audio) and
+    the digital voice modes (metrics only)."""
+    g = golden("chain_rawdig")
+    fs, n, seed = (int(v) for v in g["args"])
+    iq = S.nbfm_bank_c64(n, fs, seed=seed)
+    for ci, off in enumerate(g["offs"]):
+        audio, met = wh.process_channel_dsp_stateless(iq, fs, wh.ChannelConfig(mode="raw", offset_hz=float(off)))
+        assert audio.dtype == np.float32 and audio.shape == (2 * n,)
+        assert peak_rel_err(audio, g[f"raw{ci}_audio"]) <= TOL
+        assert np.abs(np.array([met["rssi_db"], met["signal_power_db"]]) - g[f"raw{ci}_met"]).max() <= 2e-4
+        for mode in ("p25", "dmr", "nxdn", "dstar", "ysf"):
+            audio, met = wh.process_channel_dsp_stateless(iq, fs, wh.ChannelConfig(mode=mode, offset_hz=float(off)))
+            assert audio is None
+            assert np.abs(np.array([met["rssi_db"], met["signal_power_db"]]) - g[f"dig{ci}_met"]).max() <= 2e-4
+    audio, met = wh.process_channel_dsp_stateless((iq * 40).astype(np.complex64), fs, wh.ChannelConfig(mode="raw"))
+    assert audio is None and "signal_power_db" not in met and abs(met["rssi_db"] - float(g["loud_rssi"])) <= 2e-4
+    bad = iq.copy()
+    bad[5] = np.nan
+    assert wh.process_channel_dsp_stateless(bad, fs, wh.ChannelConfig(mode="raw")) == (None, {})
+
+
+def test_chain_sam(wh, golden):
+    """"sam" mode (dsp/sam.py:132-269 through capture.py:386-399): float64 carrier-recovery PLL per chunk,
+    sideband selection, then the AM chain; single-channel operator and a 3-channel bank."""
+    from test_oracle_golden import sam_cases
+    g = golden("chain_sam")
+    for tag, fs, iq, off, kw in sam_cases(g):
+        cfg = wh.ChannelConfig(mode="sam", offset_hz=off, **kw)
+        audio, met = wh.process_channel_dsp_stateless(iq, fs, cfg)
+        assert audio is not None and audio.shape == g[f"{tag}_audio"].shape, tag
+        assert peak_rel_err(audio, g[f"{tag}_audio"]) <= TOL, tag
+        assert np.abs(np.array([met["rssi_db"], met["signal_power_db"]]) - g[f"{tag}_met"]).max() <= 2e-4, tag
+    tag, fs, iq, off, kw = next(sam_cases(g))
+    cfgs = [wh.ChannelConfig(mode="sam", offset_hz=o, **kw) for o in (off - 50.0, off, off + 50.0)]
+    res = wh.ChannelBank(fs, iq.shape[0], cfgs).process(iq)
+    assert peak_rel_err(res[1][0], g[f"{tag}_audio"]) <= TOL
+    assert res[0][0] is not None and res[2][0] is not None

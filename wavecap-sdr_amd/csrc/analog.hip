@@ -156,9 +156,10 @@ struct FmArgs {
     const double *taps; // [ntaps]
     int fmt, N, K, n_out, ntaps, down, d0, TO;
     float scale;        // fs / (2 pi 75000)
-    int demod;          // 0 FM discriminator, 1 AM envelope, 2 SSB product detector
+    int demod;          // 0 FM discriminator, 1 AM envelope, 2 SSB product detector, 3/4/5 SAM dsb/usb/lsb
     double bfo_c;       // 2 pi bfo_hz (SSB), sample_rate in fs_d
     double fs_d;
+    double pll_alpha, pll_beta;   // SAM carrier-recovery PLL loop filter (dsp/sam.py:55-66)
 };
 
 constexpr int FM_MAX_SPAN = 8192;    // floats of fm kept in LDS (32 KiB -> 4 workgroups per CU)
@@ -308,6 +309,43 @@ __global__ __launch_bounds__(256) void chan_front_kernel(FmArgs a) {
         atomicAdd(acc, red[0] + red[1] + red[2] + red[3]);
         atomicAdd(acc + 1, red[4] + red[5] + red[6] + red[7]);
     }
+}
+
+// Synchronous AM front (dsp/sam.py:73-122 CarrierRecoveryPLL.process + :219-232 sideband selection): a
+// type-2 PLL that feeds back every sample, fresh per chunk (sam_demod_simple passes no pll_state), all in
+// float64 like the reference's Python floats / complex128; outputs rounded to float32.  One lane per
+// (chunk, channel) row; lanes of a wave read the same input sample (broadcast).
+__global__ __launch_bounds__(64) void sam_front_kernel(FmArgs a, int n_rows) {
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= n_rows) return;
+    const int chunk = r / a.K, k = r - chunk * a.K;
+    const int N = a.N;
+    const float c = a.nco_c[k];
+    const bool do_mix = c != 0.0f;
+    const size_t in_base = (size_t)chunk * N;
+    float *row = a.fm_out + (size_t)r * N;
+    const double PI_D = 3.141592653589793;
+    double phase = 0.0, integ = 0.0;
+    double p_base = 0.0;
+    for (int n = 0; n < N; ++n) {
+        float2 x = mix(load_iq(a.in, a.fmt, in_base + n), c, n, do_mix);
+        p_base += (double)(x.x * x.x + x.y * x.y);
+        double sn, cs;
+        sincos(phase, &sn, &cs);
+        const double lr = cs, li = -sn;                       // exp(-1j * phase)
+        const double xr = (double)x.x, xi = (double)x.y;
+        const double mr = __dsub_rn(__dmul_rn(xr, lr), __dmul_rn(xi, li));
+        const double mi = __dadd_rn(__dmul_rn(xr, li), __dmul_rn(xi, lr));
+        const float ci = (float)mr, cq = (float)mi;
+        row[n] = a.demod == 3 ? ci : (a.demod == 4 ? __fadd_rn(ci, cq) : __fsub_rn(ci, cq));
+        const double pe = atan2(mi, __dadd_rn(fabs(mr), 1e-10));
+        integ = __dadd_rn(integ, __dmul_rn(a.pll_beta, pe));
+        const double fc = __dadd_rn(__dmul_rn(a.pll_alpha, pe), integ);
+        phase = __dadd_rn(phase, fc);
+        if (phase > PI_D) phase = __dsub_rn(phase, 2 * PI_D);
+        else if (phase < -PI_D) phase = __dadd_rn(phase, 2 * PI_D);
+    }
+    a.acc[(size_t)r * 2] = p_base;
 }
 
 // Sequential IIR stages on one (chunk, channel) row, zero initial state per chunk (stateless
@@ -593,7 +631,7 @@ extern "C" int wh_chanbank_create(wh_chanbank **out, const wh_chanbank_cfg *c) {
     if (!out || !c || !c->h_offsets_hz) return set_err(WH_E_ARG, "wh_chanbank_create: null");
     const bool resample = c->ntaps > 0;
     if (c->n_channels < 1 || c->n_channels > 65535 || c->chunk_len < 2 || c->chunk_len > (1 << 24) ||
-        (resample && (!c->h_taps || c->up < 1 || c->down < 1)) || c->n_out < 1 || c->demod < 0 || c->demod > 2 ||
+        (resample && (!c->h_taps || c->up < 1 || c->down < 1)) || c->n_out < 1 || c->demod < 0 || c->demod > 5 ||
         (c->input_format != 0 && c->input_format != 1) || c->n_stages < 0 || c->n_stages > MAX_STAGES ||
         (c->n_stages > 0 && !c->h_stages) || c->post < 0 || c->post > 1 || (!resample && c->n_out != c->chunk_len))
         return set_err(WH_E_ARG, "wh_chanbank_create: bad configuration");
@@ -712,6 +750,8 @@ extern "C" int wh_chanbank_run(wh_chanbank *b, const void *d_in, size_t n_chunks
     a.demod = c.demod;
     a.bfo_c = 2.0 * M_PI * c.bfo_hz;   // Python: (2j*np.pi) * offset_hz
     a.fs_d = (double)c.sample_rate;
+    a.pll_alpha = c.pll_alpha;
+    a.pll_beta = c.pll_beta;
     if (b->fused) {
         int tiles = (c.n_out + b->TO - 1) / b->TO;
         hipLaunchKernelGGL(fmbank_fused_kernel, dim3(tiles, c.n_channels, (unsigned)n_chunks), dim3(256), b->smem, st, a);
@@ -719,7 +759,10 @@ extern "C" int wh_chanbank_run(wh_chanbank *b, const void *d_in, size_t n_chunks
     } else {
         int per_block = 4 * 63 * 16;
         int blocks = (c.chunk_len + per_block - 1) / per_block;
-        hipLaunchKernelGGL(chan_front_kernel, dim3(blocks, c.n_channels, (unsigned)n_chunks), dim3(256), 0, st, a);
+        if (c.demod >= 3)
+            hipLaunchKernelGGL(sam_front_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st, a, (int)rows);
+        else
+            hipLaunchKernelGGL(chan_front_kernel, dim3(blocks, c.n_channels, (unsigned)n_chunks), dim3(256), 0, st, a);
         WH_LAUNCH_CHECK();
         if (c.n_stages > 0 || c.agc) {
             AgcDev g;
@@ -767,7 +810,7 @@ extern "C" int wh_channel_signal_metrics(const void *d_in, int input_format, siz
     FmArgs a;
     a.in = d_in; a.audio = nullptr; a.acc = d_acc; a.fm_out = d_rows; a.nco_c = d_nco; a.taps = nullptr;
     a.fmt = input_format; a.N = (int)n; a.K = K; a.n_out = 0; a.ntaps = 0; a.down = 1; a.d0 = 0; a.TO = 1;
-    a.scale = 0.f; a.demod = 1; a.bfo_c = 0.0; a.fs_d = (double)sample_rate;
+    a.scale = 0.f; a.demod = 1; a.bfo_c = 0.0; a.fs_d = (double)sample_rate; a.pll_alpha = a.pll_beta = 0.0;
     const int per_block = 4 * 63 * 16;
     hipLaunchKernelGGL(chan_front_kernel, dim3((unsigned)((n + per_block - 1) / per_block), K, 1), dim3(256), 0, st, a);
     WH_LAUNCH_CHECK();

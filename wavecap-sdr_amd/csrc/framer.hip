@@ -47,7 +47,52 @@ __global__ void clip_kernel(const float *in, float *out, size_t n) {
     }
 }
 
+// validate_audio_samples (validation.py:41-52) + the signal-power metric (capture.py:436-437) in one pass.
+__global__ __launch_bounds__(256) void audio_stats_kernel(const float *x, size_t n, float *out) {
+    double p = 0.0;
+    float mx = 0.f;
+    int bad = 0;
+    for (size_t i = threadIdx.x; i < n; i += 256) {
+        float v = x[i];
+        p += (double)v * (double)v;
+        mx = fmaxf(mx, fabsf(v));
+        if (!(fabsf(v) <= 3.4028235e38f)) bad = 1;
+    }
+    __shared__ double sp[256];
+    __shared__ float sm[256];
+    __shared__ int sb[256];
+    sp[threadIdx.x] = p; sm[threadIdx.x] = mx; sb[threadIdx.x] = bad;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            sp[threadIdx.x] += sp[threadIdx.x + w];
+            sm[threadIdx.x] = fmaxf(sm[threadIdx.x], sm[threadIdx.x + w]);
+            sb[threadIdx.x] |= sb[threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[0] = (float)(sp[0] / (double)n);
+        out[1] = sm[0];
+        out[2] = sb[0] ? 0.f : 1.f;
+    }
+}
+
 }  // namespace
+
+extern "C" int wh_audio_stats(const float *d_x, size_t n, float *h_out, void *stream) {
+    if (!d_x || !h_out || n == 0) return set_err(WH_E_ARG, "wh_audio_stats: bad arguments");
+    hipStream_t st = as_stream(stream);
+    float *d_out = nullptr;
+    WH_HIP(hipMallocAsync(reinterpret_cast<void **>(&d_out), 3 * sizeof(float), st));
+    hipLaunchKernelGGL(audio_stats_kernel, dim3(1), dim3(256), 0, st, d_x, n, d_out);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(h_out, d_out, 3 * sizeof(float), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFreeAsync(d_out, st);
+    if (e != hipSuccess) return set_err(WH_E_HIP, hipGetErrorString(e));
+    return WH_OK;
+}
 
 extern "C" int wh_sync_correlate(const float *d_soft, size_t n, size_t stride, int n_channels, const float *d_hist_in,
                                  float *d_hist_out, float *d_scores, void *stream) {

@@ -59,6 +59,8 @@ class ChanBankCfg(C.Structure):
         ("down", c_int),
         ("d0", c_int),
         ("n_out", c_int),
+        ("pll_alpha", c_double),
+        ("pll_beta", c_double),
     ]
 
 
@@ -73,6 +75,7 @@ PROTOTYPES = {
     "wh_pack_f32_pcm16": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "wh_clip_f32": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "wh_sync_correlate": (c_int, [c_void_p, c_size_t, c_size_t, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "wh_audio_stats": (c_int, [c_void_p, c_size_t, C.POINTER(c_float), c_void_p]),
     "wh_nco_mix": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
     "wh_fm_discriminate": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "wh_resampler_create": (c_int, [C.POINTER(c_void_p), C.POINTER(c_double), c_int, c_int, c_int, c_int]),

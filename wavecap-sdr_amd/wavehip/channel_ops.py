@@ -13,9 +13,9 @@ identical.
 
 `process_channel_dsp_stateless` is the single-channel drop-in with the reference's exact
 signature and error convention (non-finite input or audio failing validate_audio_samples ->
-(None, metrics); capture.py:323-325, 433-435).  Supported modes: "nbfm", "wbfm", "am", "ssb"
-with their filter flags.  "sam", "raw", digital modes and spectral noise reduction raise
-NotImplementedError -- the integration stub keeps routing those to the reference implementation
+(None, metrics); capture.py:323-325, 433-435).  Supported modes: "nbfm", "wbfm", "am", "ssb", "sam"
+with their filter flags, "raw" (mixed IQ, interleaved) and the digital voice modes (metrics only,
+capture.py:424-430).  Spectral noise reduction raises NotImplementedError -- the integration stub keeps routing those to the reference implementation
 (INTEGRATION.md); nothing here falls back to a CPU path.
 """
 
@@ -68,6 +68,8 @@ class ChannelConfig:
     agc_target_db: float = -20.0
     notch_frequencies: list = field(default_factory=list)
     enable_noise_reduction: bool = False
+    sam_sideband: str = "dsb"
+    sam_pll_bandwidth_hz: float = 50.0
 
 
 def resample_design(in_rate: int, out_rate: int):
@@ -82,7 +84,7 @@ def resample_design(in_rate: int, out_rate: int):
 
 
 def _unsupported(cfg) -> str | None:
-    if cfg.mode not in ("nbfm", "wbfm", "am", "ssb"):
+    if cfg.mode not in ("nbfm", "wbfm", "am", "ssb", "sam"):
         return f"mode {cfg.mode!r}"
     if getattr(cfg, "enable_noise_reduction", False) and cfg.mode in ("nbfm", "wbfm"):
         return "spectral noise reduction"
@@ -128,7 +130,8 @@ def _notches(cfg, sample_rate: int):
 
 
 def build_chain(cfg, sample_rate: int):
-    """-> (demod, bfo_hz, stages, agc tuple | None, post) in the reference's application order."""
+    """-> (demod, bfo_hz, stages, agc tuple | None, post) in the reference's application order
+    (SAM's PLL coefficients come from sam_pll_coefficients)."""
     mode = cfg.mode
     stages = []
     agc = None
@@ -154,8 +157,8 @@ def build_chain(cfg, sample_rate: int):
         stages += _notches(cfg, sample_rate)
     else:
         post = 1
-        if mode == "am":                                # dsp/am.py:45-141
-            demod = 1
+        if mode in ("am", "sam"):                       # dsp/am.py:45-141; dsp/sam.py:132-269 (same chain after the front)
+            demod = 1 if mode == "am" else {"usb": 4, "lsb": 5}.get(str(getattr(cfg, "sam_sideband", "dsb")).lower(), 3)
             if cfg.enable_am_highpass and cfg.am_highpass_hz > 0:
                 ba = _butter("high", sample_rate, cfg.am_highpass_hz)
                 if ba is not None:
@@ -171,7 +174,8 @@ def build_chain(cfg, sample_rate: int):
                 ba = _butter("band", sample_rate, (cfg.ssb_bandpass_low_hz, cfg.ssb_bandpass_high_hz))
                 if ba is not None:
                     stages.append(_stage(*ba, True))
-        stages += _notches(cfg, sample_rate)
+        if mode != "sam":                               # capture.py:386-399 passes no notch list to sam_demod_simple
+            stages += _notches(cfg, sample_rate)
         if cfg.enable_agc:                              # dsp/agc.py:169-242, attack 5 ms / release 50 ms
             att = (5.0 / 1000.0) * sample_rate
             rel = (50.0 / 1000.0) * sample_rate
@@ -184,6 +188,13 @@ def build_chain(cfg, sample_rate: int):
     return demod, float(bfo), stages, agc, post
 
 
+def sam_pll_coefficients(sample_rate: int, loop_bandwidth: float, damping: float = 0.707):
+    """dsp/sam.py:55-66 (sample_rate as float, Python-float arithmetic in the reference's order)."""
+    fs = float(sample_rate)
+    omega_n = 2 * np.pi * loop_bandwidth
+    return float(2 * damping * omega_n / fs), float((omega_n ** 2) / (fs ** 2))
+
+
 def _chain_key(cfg):
     return (cfg.mode, int(cfg.audio_rate), bool(cfg.enable_deemphasis), float(cfg.deemphasis_tau_us),
             bool(cfg.enable_mpx_filter), float(cfg.mpx_cutoff_hz), bool(cfg.enable_fm_highpass),
@@ -191,7 +202,8 @@ def _chain_key(cfg):
             bool(cfg.enable_am_highpass), float(cfg.am_highpass_hz), bool(cfg.enable_am_lowpass),
             float(cfg.am_lowpass_hz), bool(cfg.enable_ssb_bandpass), float(cfg.ssb_bandpass_low_hz),
             float(cfg.ssb_bandpass_high_hz), str(cfg.ssb_mode), float(cfg.ssb_bfo_offset_hz),
-            bool(cfg.enable_agc), float(cfg.agc_target_db), tuple(getattr(cfg, "notch_frequencies", None) or ()))
+            bool(cfg.enable_agc), float(cfg.agc_target_db), tuple(getattr(cfg, "notch_frequencies", None) or ()),
+            str(getattr(cfg, "sam_sideband", "dsb")).lower(), float(getattr(cfg, "sam_pll_bandwidth_hz", 50.0)))
 
 
 class ChannelBank:
@@ -224,6 +236,8 @@ class ChannelBank:
         cfg.h_offsets_hz = _lib.dptr(offs, "i32")
         cfg.input_format = self.input_format
         cfg.demod, cfg.bfo_hz, cfg.post = demod, bfo, post
+        if demod >= 3:
+            cfg.pll_alpha, cfg.pll_beta = sam_pll_coefficients(self.sample_rate, float(getattr(c0, "sam_pll_bandwidth_hz", 50.0)))
         keep = [offs]
         cfg.n_stages = len(stages)
         if stages:
@@ -338,6 +352,41 @@ def update_signal_metrics(samples, sample_rate: int, offsets_hz, input_format: s
 
 _bank_cache: dict[tuple, ChannelBank] = {}
 
+DIGITAL_MODES = ("p25", "dmr", "nxdn", "dstar", "ysf")      # capture.py:424
+
+
+def _raw_or_digital(samples, sample_rate: int, cfg) -> tuple[np.ndarray | None, dict[str, Any]]:
+    """capture.py:415-430: "raw" returns the frequency-shifted IQ interleaved as float32; the digital voice
+    modes return no audio, only rssi_db / signal_power_db of the shifted IQ (their decoders are stateful and
+    run elsewhere).  Mix (A2 kernel) and the power / validation reduction run on the device."""
+    torch = _lib.require_gpu()
+    metrics: dict[str, Any] = {}
+    x = np.ascontiguousarray(samples, dtype=np.complex64)
+    if not np.isfinite(x.view(np.float32)).all():          # capture.py:323-325
+        logger.warning(f"Channel {getattr(cfg, 'id', '?')}: non-finite IQ samples, dropping DSP chunk")
+        return None, metrics
+    d = torch.from_numpy(x).cuda()
+    off = float(cfg.offset_hz)
+    if off != 0.0:
+        base = torch.empty_like(d)
+        _lib.check(_lib.lib.wh_nco_mix(d.data_ptr(), base.data_ptr(), x.shape[0], int(round(off)), int(sample_rate),
+                                       _lib.stream_ptr(torch)), "wh_nco_mix")
+    else:
+        base = d
+    st = (C.c_float * 3)()
+    flat = torch.view_as_real(base)
+    _lib.check(_lib.lib.wh_audio_stats(flat.data_ptr(), 2 * x.shape[0], st, _lib.stream_ptr(torch)), "wh_audio_stats")
+    mean_sq, max_abs, finite = float(st[0]), float(st[1]), st[2] >= 0.5
+    rssi = float(10.0 * np.log10(np.float32(2.0 * mean_sq) + np.float32(1e-10)))   # mean |base|^2 = 2 mean(re^2, im^2)
+    metrics["rssi_db"] = rssi
+    if cfg.mode in DIGITAL_MODES:
+        metrics["signal_power_db"] = rssi
+        return None, metrics
+    if not finite or max_abs > AUDIO_MAX_ABS:              # validation.py:41-52
+        return None, metrics
+    metrics["signal_power_db"] = float(10.0 * np.log10(np.float32(mean_sq) + np.float32(1e-10)))
+    return flat.reshape(-1).cpu().numpy(), metrics
+
 
 def process_channel_dsp_stateless(samples, sample_rate: int, cfg) -> tuple[np.ndarray | None, dict[str, Any]]:
     """Drop-in for capture.py:298 (single channel).  Banks are cached per
@@ -345,6 +394,8 @@ def process_channel_dsp_stateless(samples, sample_rate: int, cfg) -> tuple[np.nd
     metrics: dict[str, Any] = {}
     if samples.size == 0:
         return None, metrics
+    if cfg.mode == "raw" or cfg.mode in DIGITAL_MODES:
+        return _raw_or_digital(samples, sample_rate, cfg)
     why = _unsupported(cfg)
     if why:
         raise NotImplementedError(f"wavehip: {why} is not implemented on the device")
