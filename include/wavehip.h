@@ -113,6 +113,11 @@ typedef struct wh_chanbank_cfg {
     int ntaps, up, down, d0;
     int n_out;              /* ceil(N*up/down), or N when ntaps == 0 */
     double pll_alpha, pll_beta; /* demod 3..5: 2*damping*omega_n/fs, omega_n^2/fs^2 */
+    int noise_reduction;    /* post 0 only: spectral_noise_reduction (dsp/filters.py:346-460) between the IIR stages and
+                               rms_normalize; chunks shorter than 1024 pass through; otherwise the row shrinks to
+                               ((N-1024)/512)*512 + 1024 samples and n_out must be computed from that length */
+    float nr_reduction_linear;      /* float32(10^(noise_reduction_db/20)) */
+    const float *h_nr_window;       /* float32[1024] scipy.signal.windows.hann(1024, sym=False) */
 } wh_chanbank_cfg;
 int wh_chanbank_create(wh_chanbank **out, const wh_chanbank_cfg *cfg);
 int wh_chanbank_run(wh_chanbank *b, const void *d_in, size_t n_chunks, float *d_audio, float *d_metrics,

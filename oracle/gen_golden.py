@@ -240,6 +240,42 @@ def gen_sam():
     save("chain_sam", **out)
 
 
+def gen_nr():
+    """A14: spectral_noise_reduction (dsp/filters.py:346-460) as reached through the nbfm / wbfm branches of
+    _process_channel_dsp_stateless with enable_noise_reduction=True."""
+    out = {}
+    offs = S.nbfm_bank_offsets()
+    cases = [
+        # tag, mode, fs, n, seed, channel offset, extra cfg
+        ("nbfm24", "nbfm", 2400000, 120000, 570, offs[13], dict()),                 # 233 frames, row shrinks to 119808
+        ("nbfm24_18db", "nbfm", 2400000, 60000, 571, offs[20], dict(noise_reduction_db=18.0)),
+        ("wbfm24", "wbfm", 2400000, 60000, 572, 200000.0, dict()),                  # de-emphasis + MPX, then NR
+        ("nbfm48", "nbfm", 48000, 4800, 573, 6000.0, dict()),                       # no resampling: audio = 4608 samples
+        ("short", "nbfm", 48000, 1000, 574, 6000.0, dict()),                        # < 1024 samples: passes through
+    ]
+    for tag, mode, fs, n, seed, off, kw in cases:
+        if fs == 2400000 and mode == "nbfm":
+            iq = S.nbfm_bank_c64(n, fs, seed=seed)
+        elif mode == "wbfm":
+            iq = S.fm_tone_c64(n, fs, seed=seed, carrier_hz=off, noise_amp=0.2)
+        else:
+            iq = S.fm_tone_c64(n, fs, seed=seed, audio_hz=700.0, deviation=3000.0, carrier_hz=off, noise_amp=0.2)
+        cfg = _cfg(mode, off) if mode == "nbfm" else rc.ChannelConfig(id="w", capture_id="c", mode="wbfm", offset_hz=off)
+        cfg.enable_noise_reduction = True
+        for k, v in kw.items():
+            setattr(cfg, k, v)
+        rc._get_freq_shift_exp.cache_clear()
+        audio, met = rc._process_channel_dsp_stateless(iq, fs, cfg)
+        assert audio is not None, tag
+        out[f"{tag}_sha"] = np.array(S.sha256(iq))
+        out[f"{tag}_audio"] = audio
+        out[f"{tag}_met"] = np.array([met["rssi_db"], met["signal_power_db"]])
+        out[f"{tag}_args"] = np.array([fs, n, seed, off, kw.get("noise_reduction_db", 12.0)], dtype=np.float64)
+        out[f"{tag}_mode"] = np.array(mode)
+    out["tags"] = np.array([c[0] for c in cases])
+    save("chain_nr", **out)
+
+
 def gen_a7():
     out = {}
     cases = [(1_000_000, 25000, 40, 701), (8_000_000, 25000, 320, 702), (10_000_000, 9765, 1024, 703)]
@@ -540,7 +576,7 @@ def gen_lsm():
     save("lsm", **out)
 
 
-ALL = dict(sam=gen_sam, rawdig=gen_rawdig, lsm=gen_lsm, framer=gen_framer, cqpsk=gen_cqpsk, trunk=gen_trunk, a1=gen_a1, a2=gen_a2, a3=gen_a3, a6=gen_a6, chain=gen_chain, a7=gen_a7, a8=gen_a8, c4fm=gen_c4fm)
+ALL = dict(nr=gen_nr, sam=gen_sam, rawdig=gen_rawdig, lsm=gen_lsm, framer=gen_framer, cqpsk=gen_cqpsk, trunk=gen_trunk, a1=gen_a1, a2=gen_a2, a3=gen_a3, a6=gen_a6, chain=gen_chain, a7=gen_a7, a8=gen_a8, c4fm=gen_c4fm)
 
 if __name__ == "__main__":
     import logging

@@ -437,8 +437,36 @@ def sam_demod(iq: np.ndarray, sample_rate: int, audio_rate: int = 48_000, sideba
     return audio
 
 
+def spectral_noise_reduction(x: np.ndarray, reduction_db: float = 12.0, fft_size: int = 1024) -> np.ndarray:
+    """dsp/filters.py:346-460 (overlap 0.5): float32 STFT / ISTFT (numpy 2 keeps float32 in rfft/irfft),
+    per-bin 10th-percentile noise floor, gain max(1 - (floor*10^(dB/20)/|X|)^2, 0.1), overlap-add over the
+    summed squared window.  Returns (n_frames-1)*hop + fft_size samples (<= len(x))."""
+    if x.size == 0 or x.size < fft_size:
+        return x.astype(np.float32, copy=False)
+    hop = int(fft_size * 0.5)
+    win = _sig.windows.hann(fft_size, sym=False).astype(np.float32)
+    nf = (len(x) - fft_size) // hop + 1
+    length = (nf - 1) * hop + fft_size
+    idx = np.arange(fft_size)[None, :] + hop * np.arange(nf)[:, None]
+    spec = np.fft.rfft(x[idx] * win, axis=1).astype(np.complex64)
+    mag = np.abs(spec)
+    floor = np.percentile(mag, 10, axis=0)
+    scaled = floor * 10 ** (reduction_db / 20.0)
+    gain = np.maximum(np.maximum(0.0, 1.0 - (scaled / np.maximum(mag, 1e-10)) ** 2), 0.1)
+    clean = (mag * gain) * np.exp(1j * np.angle(spec))
+    frames = np.fft.irfft(clean, n=fft_size, axis=1).astype(np.float32) * win
+    out = np.zeros(length, dtype=np.float32)
+    wsum = np.zeros(length, dtype=np.float32)
+    for i in range(nf):
+        out[i * hop:i * hop + fft_size] += frames[i]
+        wsum[i * hop:i * hop + fft_size] += win ** 2
+    out /= np.maximum(wsum, 1e-10)
+    return out[:len(x)].astype(np.float32)
+
+
 def fm_demod_filtered(iq: np.ndarray, sample_rate: int, audio_rate: int = 48_000, *, deemphasis_tau=None,
-                      mpx_cutoff_hz=None, highpass_hz=None, lowpass_hz=None, notch_frequencies=None) -> np.ndarray:
+                      mpx_cutoff_hz=None, highpass_hz=None, lowpass_hz=None, notch_frequencies=None,
+                      noise_reduction_db=None) -> np.ndarray:
     """dsp/fm.py:228-406 with any subset of the optional IIR stages, in the reference's order:
     de-emphasis, [wbfm: MPX low-pass], high-pass, [nbfm: low-pass], notches."""
     fm = quadrature_demod(iq, sample_rate)
@@ -453,6 +481,8 @@ def fm_demod_filtered(iq: np.ndarray, sample_rate: int, audio_rate: int = 48_000
     for f in notch_frequencies or []:
         if 0 < f < sample_rate / 2:
             fm = notch_filter(fm, sample_rate, f)
+    if noise_reduction_db is not None:
+        fm = spectral_noise_reduction(fm, reduction_db=noise_reduction_db)
     fm = rms_normalize(fm, target_rms=0.18)
     audio = resample_poly(fm, sample_rate, audio_rate)
     return soft_clip_fm(audio)

@@ -117,13 +117,13 @@ __global__ void disc_kernel(const float2 *in, float *out, size_t n, float scale)
 }
 
 // ---- generic rational resampler: one wave per output ---------------------------------------
-__global__ __launch_bounds__(256) void resample_kernel(const float *x, size_t n_in, float *y, size_t n_out,
+__global__ __launch_bounds__(256) void resample_kernel(const float *x, size_t n_in, size_t x_stride, float *y, size_t n_out,
                                                        const double *h, int ntaps, int up, int down, int d0) {
     const int lane = threadIdx.x & 63;
     const size_t m = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const size_t b = blockIdx.y;
     if (m >= n_out) return;
-    const float *xb = x + b * n_in;
+    const float *xb = x + b * x_stride;
     long long base = (long long)m * down + d0;
     int j0 = (int)(base % up);
     long long q0 = (base - j0) / up;
@@ -418,13 +418,13 @@ __global__ __launch_bounds__(64) void chan_rows_kernel(float *rows, double *acc,
 // finalize.  post 0 (FM): scale by 0.18/rms (dsp/fm.py:42-62) + soft clip x0.95 (fm.py:26-39);
 // post 1 (AM/SSB with AGC): audio as is;  post 2 (AM/SSB without AGC): agc.soft_clip (agc.py:58-70)
 __global__ __launch_bounds__(256) void fmbank_finalize_kernel(float *audio, const double *acc, float *metrics,
-                                                              int N, int n_out, int post) {
+                                                              int N, int n_fm, int n_out, int post) {
     const size_t row = blockIdx.x;
     float *au = audio + row * n_out;
     const double *ac = acc + row * 2;
     float s = 1.0f;
     if (post == 0) {
-        const float mean_fm = (float)(ac[1] / (double)N);
+        const float mean_fm = (float)(ac[1] / (double)n_fm);   // n_fm < N after spectral noise reduction
         const float rms = sqrtf(mean_fm);
         if ((double)rms > 1e-4) s = (float)(0.18 / (double)rms);
     }
@@ -595,13 +595,13 @@ extern "C" void wh_resampler_destroy(wh_resampler *r) {
     delete r;
 }
 
-static int launch_resample(const float *d_x, size_t n_in, size_t batch, float *d_y, size_t n_out, const double *taps,
-                           int ntaps, int up, int down, int d0, hipStream_t st) {
+static int launch_resample(const float *d_x, size_t n_in, size_t x_stride, size_t batch, float *d_y, size_t n_out,
+                           const double *taps, int ntaps, int up, int down, int d0, hipStream_t st) {
     if (batch == 0 || n_out == 0) return WH_OK;
     for (size_t b0 = 0; b0 < batch; b0 += 65535) {
         size_t nb = batch - b0 < 65535 ? batch - b0 : 65535;
         hipLaunchKernelGGL(resample_kernel, dim3((unsigned)((n_out + 3) / 4), (unsigned)nb), dim3(256), 0, st,
-                           d_x + b0 * n_in, n_in, d_y + b0 * n_out, n_out, taps, ntaps, up, down, d0);
+                           d_x + b0 * x_stride, n_in, x_stride, d_y + b0 * n_out, n_out, taps, ntaps, up, down, d0);
         WH_LAUNCH_CHECK();
     }
     return WH_OK;
@@ -610,7 +610,106 @@ static int launch_resample(const float *d_x, size_t n_in, size_t batch, float *d
 extern "C" int wh_resampler_run(wh_resampler *r, const float *d_x, size_t n_in, size_t batch, float *d_y,
                                 size_t n_out, void *stream) {
     if (!r || !d_x || !d_y) return set_err(WH_E_ARG, "wh_resampler_run: null");
-    return launch_resample(d_x, n_in, batch, d_y, n_out, r->d_taps, r->ntaps, r->up, r->down, r->d0, as_stream(stream));
+    return launch_resample(d_x, n_in, n_in, batch, d_y, n_out, r->d_taps, r->ntaps, r->up, r->down, r->d0, as_stream(stream));
+}
+
+
+// ---- spectral noise reduction (dsp/filters.py:346-460), default-off stage of the FM chains ------------
+// STFT 1024 / hop 512 with the float32 periodic Hann window, per-bin noise floor = 10th percentile of the
+// magnitudes over the frames of the chunk, Wiener-like gain max(1 - (floor*10^(dB/20)/|X|)^2, 0.1), inverse
+// FFT, windowed overlap-add divided by the summed squared window.  The output is (n_frames-1)*512+1024
+// samples long -- SHORTER than the input when the chunk is not a whole number of hops (the reference
+// returns output[:len(x)] of a buffer that is only padded_length long).
+constexpr int NR_FFT = 1024, NR_HOP = 512, NR_BINS = 513;
+
+// in-place-free LDS Stockham radix-2, 1024 points, 256 threads; sign = -1 forward, +1 inverse (unscaled).
+// Returns the buffer holding the result.
+__device__ __forceinline__ float2 *nr_fft1024(float2 *src, float2 *dst, const float2 *tw, float sign) {
+    int n = NR_FFT, s = 1;
+    for (int st = 0; st < 10; ++st) {
+        const int m = n >> 1;
+        for (int i = threadIdx.x; i < NR_FFT / 2; i += 256) {
+            int pp = i / s, q = i - pp * s;
+            float2 c0 = src[q + s * pp];
+            float2 c1 = src[q + s * (pp + m)];
+            float2 w = tw[(size_t)pp * s];
+            w.y *= -sign;   // table holds exp(-2 pi i k / N)
+            dst[q + s * 2 * pp] = make_float2(c0.x + c1.x, c0.y + c1.y);
+            float2 d = make_float2(c0.x - c1.x, c0.y - c1.y);
+            dst[q + s * (2 * pp + 1)] = make_float2(d.x * w.x - d.y * w.y, d.x * w.y + d.y * w.x);
+        }
+        __syncthreads();
+        float2 *t = src; src = dst; dst = t;
+        n = m; s <<= 1;
+    }
+    return src;
+}
+
+__global__ __launch_bounds__(256) void nr_stft_kernel(const float *rows, int N, int F, const float *window,
+                                                      const float2 *tw, float2 *stft, float *magT) {
+    __shared__ float2 buf[2][NR_FFT];
+    const int f = blockIdx.x, r = blockIdx.y;
+    const float *x = rows + (size_t)r * N + (size_t)f * NR_HOP;
+    for (int t = threadIdx.x; t < NR_FFT; t += 256) buf[0][t] = make_float2(x[t] * window[t], 0.0f);
+    __syncthreads();
+    const float2 *X = nr_fft1024(buf[0], buf[1], tw, -1.0f);
+    for (int b = threadIdx.x; b < NR_BINS; b += 256) {
+        float2 v = X[b];
+        stft[((size_t)r * F + f) * NR_BINS + b] = v;
+        magT[((size_t)r * NR_BINS + b) * F + f] = hypotf(v.x, v.y);
+    }
+}
+
+__global__ __launch_bounds__(256) void nr_istft_kernel(float *rows, int N, int F, const float *window, const float2 *tw,
+                                                       const float2 *stft, const float *sel, int k_lo, float gamma,
+                                                       float lin) {
+    __shared__ float2 buf[2][NR_FFT];
+    const int f = blockIdx.x, r = blockIdx.y;
+    for (int b = threadIdx.x; b < NR_BINS; b += 256) {
+        float2 v = stft[((size_t)r * F + f) * NR_BINS + b];
+        const float *q = sel + ((size_t)r * NR_BINS + b) * 2;
+        float lo = q[0], hi = q[1];
+        float d = hi - lo;   // np.percentile 'linear': a + (b-a) t, evaluated from b when t >= 0.5
+        float nf = gamma >= 0.5f ? hi - d * (1.0f - gamma) : lo + d * gamma;
+        float mag = hypotf(v.x, v.y);
+        float ratio = (nf * lin) / fmaxf(mag, 1e-10f);
+        float g = fmaxf(fmaxf(0.0f, 1.0f - ratio * ratio), 0.1f);
+        float2 y = make_float2(v.x * g, v.y * g);   // = |X| g exp(j arg X)
+        if (b == 0 || b == NR_FFT / 2) y.y = 0.0f;    // c2r ignores the imaginary part of DC / Nyquist
+        buf[0][b] = y;
+        if (b > 0 && b < NR_FFT / 2) buf[0][NR_FFT - b] = make_float2(y.x, -y.y);
+    }
+    __syncthreads();
+    const float2 *xt = nr_fft1024(buf[0], buf[1], tw, 1.0f);
+    float *o = rows + (size_t)r * N + (size_t)f * NR_HOP;
+    for (int t = threadIdx.x; t < NR_FFT; t += 256) {
+        float v = xt[t].x * (1.0f / NR_FFT);
+        atomicAdd(o + t, v * window[t]);   // <= 2 contributions per sample: float add is commutative, so deterministic
+    }
+}
+
+__global__ __launch_bounds__(256) void nr_norm_kernel(float *rows, int N, int F, const float *window, double *acc) {
+    const int r = blockIdx.x;
+    float *o = rows + (size_t)r * N;
+    const int L = (F - 1) * NR_HOP + NR_FFT;
+    double ss = 0.0;
+    for (int t = threadIdx.x; t < L; t += 256) {
+        int f1 = t / NR_HOP, i1 = t - f1 * NR_HOP;
+        float ws = 0.0f;
+        if (f1 >= 1) { float w = window[i1 + NR_HOP]; ws += w * w; }
+        if (f1 < F) { float w = window[i1]; ws += w * w; }
+        float v = o[t] / fmaxf(ws, 1e-10f);
+        o[t] = v;
+        ss += (double)v * (double)v;
+    }
+    __shared__ double red[256];
+    red[threadIdx.x] = ss;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) acc[(size_t)r * 2 + 1] = red[0];
 }
 
 struct wh_chanbank {
@@ -625,6 +724,11 @@ struct wh_chanbank {
     int TO = 128;
     size_t smem = 0;
     int post = 0;
+    // spectral noise reduction workspace
+    bool nr = false;
+    int nr_frames = 0, nr_len = 0;
+    float *d_nr_win = nullptr, *d_nr_mag = nullptr, *d_nr_sel = nullptr;
+    float2 *d_nr_tw = nullptr, *d_nr_stft = nullptr;
 };
 
 extern "C" int wh_chanbank_create(wh_chanbank **out, const wh_chanbank_cfg *c) {
@@ -633,7 +737,7 @@ extern "C" int wh_chanbank_create(wh_chanbank **out, const wh_chanbank_cfg *c) {
     if (c->n_channels < 1 || c->n_channels > 65535 || c->chunk_len < 2 || c->chunk_len > (1 << 24) ||
         (resample && (!c->h_taps || c->up < 1 || c->down < 1)) || c->n_out < 1 || c->demod < 0 || c->demod > 5 ||
         (c->input_format != 0 && c->input_format != 1) || c->n_stages < 0 || c->n_stages > MAX_STAGES ||
-        (c->n_stages > 0 && !c->h_stages) || c->post < 0 || c->post > 1 || (!resample && c->n_out != c->chunk_len))
+        (c->n_stages > 0 && !c->h_stages) || c->post < 0 || c->post > 1)
         return set_err(WH_E_ARG, "wh_chanbank_create: bad configuration");
     for (int i = 0; i < c->n_stages; ++i)
         if (c->h_stages[i].n < 1 || c->h_stages[i].n > MAX_ORD || c->h_stages[i].a[0] == 0.0)
@@ -645,6 +749,31 @@ extern "C" int wh_chanbank_create(wh_chanbank **out, const wh_chanbank_cfg *c) {
     b->cfg.h_taps = nullptr;
     b->cfg.h_stages = nullptr;
     b->post = c->post == 0 ? 0 : (c->agc ? 1 : 2);
+    if (c->noise_reduction) {
+        if (!c->h_nr_window || c->post != 0 || !(c->nr_reduction_linear > 0.0f))
+            return set_err(WH_E_ARG, "wh_chanbank_create: noise reduction needs the FM chain, a window and a positive factor");
+        if (c->chunk_len >= NR_FFT) {   // shorter chunks pass through unchanged (dsp/filters.py:388-389)
+            b->nr = true;
+            b->nr_frames = (c->chunk_len - NR_FFT) / NR_HOP + 1;
+            b->nr_len = (b->nr_frames - 1) * NR_HOP + NR_FFT;
+            std::vector<float2> tw(NR_FFT);
+            for (int m = 0; m < NR_FFT; ++m) {
+                double ang = -2.0 * M_PI * (double)m / (double)NR_FFT;
+                tw[m] = make_float2((float)cos(ang), (float)sin(ang));
+            }
+            WH_HIP(hipMalloc(&b->d_nr_win, NR_FFT * sizeof(float)));
+            WH_HIP(hipMalloc(&b->d_nr_tw, NR_FFT * sizeof(float2)));
+            WH_HIP(hipMemcpy(b->d_nr_win, c->h_nr_window, NR_FFT * sizeof(float), hipMemcpyHostToDevice));
+            WH_HIP(hipMemcpy(b->d_nr_tw, tw.data(), NR_FFT * sizeof(float2), hipMemcpyHostToDevice));
+        }
+    }
+    b->cfg.h_nr_window = nullptr;
+    {
+        const int n_eff = b->nr ? b->nr_len : c->chunk_len;
+        const long long n_up = (long long)n_eff * (resample ? c->up : 1);
+        const long long want = resample ? n_up / c->down + (n_up % c->down ? 1 : 0) : n_eff;
+        if (want != c->n_out) return set_err(WH_E_ARG, "wh_chanbank_create: n_out must be %lld for this configuration", want);
+    }
     std::vector<float> nco(c->n_channels);
     for (int k = 0; k < c->n_channels; ++k) nco[k] = c->h_offsets_hz[k] == 0 ? 0.0f : nco_const(c->h_offsets_hz[k], c->sample_rate);
     WH_HIP(hipMalloc(&b->d_nco, nco.size() * sizeof(float)));
@@ -676,7 +805,7 @@ extern "C" int wh_chanbank_create(wh_chanbank **out, const wh_chanbank_cfg *c) {
     }
     // fused path: plain FM (no IIR stage, no AGC), pure decimation, everything fits in LDS
     b->fused = false;
-    if (c->demod == 0 && c->n_stages == 0 && !c->agc && c->post == 0 && resample && c->up == 1 &&
+    if (c->demod == 0 && c->n_stages == 0 && !c->agc && c->post == 0 && !b->nr && resample && c->up == 1 &&
         c->ntaps <= FM_MAX_TAPS) {
         int TO = 256;
         while (TO > 8 && c->ntaps + (TO - 1) * c->down > FM_MAX_SPAN) TO >>= 1;
@@ -699,6 +828,8 @@ extern "C" void wh_chanbank_destroy(wh_chanbank *b) {
     (void)hipFree(b->d_stages);
     (void)hipFree(b->d_acc);
     (void)hipFree(b->d_fm);
+    (void)hipFree(b->d_nr_win); (void)hipFree(b->d_nr_tw); (void)hipFree(b->d_nr_mag); (void)hipFree(b->d_nr_sel);
+    (void)hipFree(b->d_nr_stft);
     delete b;
 }
 
@@ -707,6 +838,7 @@ extern "C" size_t wh_chanbank_workspace_bytes(const wh_chanbank *b, size_t n_chu
     size_t rows = n_chunks * (size_t)b->cfg.n_channels;
     size_t bytes = rows * 2 * sizeof(double);
     if (!b->fused) bytes += rows * (size_t)b->cfg.chunk_len * sizeof(float);
+    if (b->nr) bytes += rows * (size_t)b->nr_frames * NR_BINS * (sizeof(float2) + sizeof(float)) + rows * NR_BINS * 2 * sizeof(float);
     return bytes;
 }
 
@@ -727,7 +859,15 @@ extern "C" int wh_chanbank_run(wh_chanbank *b, const void *d_in, size_t n_chunks
         b->d_acc = nullptr;
         b->d_fm = nullptr;
         WH_HIP(hipMalloc(&b->d_acc, rows * 2 * sizeof(double)));
-        if (!b->fused && resample) WH_HIP(hipMalloc(&b->d_fm, rows * (size_t)c.chunk_len * sizeof(float)));
+        if (!b->fused && (resample || b->nr)) WH_HIP(hipMalloc(&b->d_fm, rows * (size_t)c.chunk_len * sizeof(float)));
+        if (b->nr) {
+            (void)hipFree(b->d_nr_mag); (void)hipFree(b->d_nr_sel); (void)hipFree(b->d_nr_stft);
+            b->d_nr_mag = b->d_nr_sel = nullptr;
+            b->d_nr_stft = nullptr;
+            WH_HIP(hipMalloc(&b->d_nr_stft, rows * (size_t)b->nr_frames * NR_BINS * sizeof(float2)));
+            WH_HIP(hipMalloc(&b->d_nr_mag, rows * (size_t)b->nr_frames * NR_BINS * sizeof(float)));
+            WH_HIP(hipMalloc(&b->d_nr_sel, rows * (size_t)NR_BINS * 2 * sizeof(float)));
+        }
         b->cap_chunks = n_chunks;
     }
     WH_HIP(hipMemsetAsync(b->d_acc, 0, rows * 2 * sizeof(double), st));
@@ -735,7 +875,7 @@ extern "C" int wh_chanbank_run(wh_chanbank *b, const void *d_in, size_t n_chunks
     a.in = d_in;
     a.audio = d_audio;
     a.acc = b->d_acc;
-    a.fm_out = resample ? b->d_fm : d_audio;   // no resampling: rows are the audio
+    a.fm_out = (resample || b->nr) ? b->d_fm : d_audio;   // no resampling, no length change: rows are the audio
     a.nco_c = b->d_nco;
     a.taps = b->d_taps;
     a.fmt = c.input_format;
@@ -775,14 +915,39 @@ extern "C" int wh_chanbank_run(wh_chanbank *b, const void *d_in, size_t n_chunks
                                (int)rows, c.chunk_len, b->d_stages, c.n_stages, g);
             WH_LAUNCH_CHECK();
         }
+        if (b->nr) {
+            const int F = b->nr_frames;
+            if (rows > 65535) return set_err(WH_E_ARG, "wh_chanbank_run: noise reduction supports <= 65535 rows per call");
+            hipLaunchKernelGGL(nr_stft_kernel, dim3(F, (unsigned)rows), dim3(256), 0, st, b->d_fm, c.chunk_len, F,
+                               b->d_nr_win, b->d_nr_tw, b->d_nr_stft, b->d_nr_mag);
+            WH_LAUNCH_CHECK();
+            const double virt = (double)(F - 1) * 0.1;   // np.percentile(..., 10), method 'linear'
+            int k_lo = (int)floor(virt);
+            int k_hi = k_lo + 1 < F ? k_lo + 1 : F - 1;
+            hipLaunchKernelGGL(select_kth_kernel, dim3((unsigned)(rows * NR_BINS), 2), dim3(256), 0, st, b->d_nr_mag, F, k_lo,
+                               k_hi, b->d_nr_sel);
+            WH_LAUNCH_CHECK();
+            WH_HIP(hipMemsetAsync(b->d_fm, 0, rows * (size_t)c.chunk_len * sizeof(float), st));
+            hipLaunchKernelGGL(nr_istft_kernel, dim3(F, (unsigned)rows), dim3(256), 0, st, b->d_fm, c.chunk_len, F,
+                               b->d_nr_win, b->d_nr_tw, b->d_nr_stft, b->d_nr_sel, k_lo, (float)(virt - (double)k_lo),
+                               c.nr_reduction_linear);
+            WH_LAUNCH_CHECK();
+            hipLaunchKernelGGL(nr_norm_kernel, dim3((unsigned)rows), dim3(256), 0, st, b->d_fm, c.chunk_len, F, b->d_nr_win,
+                               b->d_acc);
+            WH_LAUNCH_CHECK();
+        }
+        const size_t n_fm = b->nr ? (size_t)b->nr_len : (size_t)c.chunk_len;
         if (resample) {
-            int rc = launch_resample(b->d_fm, (size_t)c.chunk_len, rows, d_audio, (size_t)c.n_out, b->d_taps, c.ntaps,
+            int rc = launch_resample(b->d_fm, n_fm, (size_t)c.chunk_len, rows, d_audio, (size_t)c.n_out, b->d_taps, c.ntaps,
                                      c.up, c.down, c.d0, st);
             if (rc != WH_OK) return rc;
+        } else if (b->nr) {   // compact the shortened rows into the audio buffer
+            WH_HIP(hipMemcpy2DAsync(d_audio, (size_t)c.n_out * sizeof(float), b->d_fm, (size_t)c.chunk_len * sizeof(float),
+                                    (size_t)c.n_out * sizeof(float), rows, hipMemcpyDeviceToDevice, st));
         }
     }
     hipLaunchKernelGGL(fmbank_finalize_kernel, dim3((unsigned)rows), dim3(256), 0, st, d_audio, b->d_acc, d_metrics,
-                       c.chunk_len, c.n_out, b->post);
+                       c.chunk_len, b->nr ? b->nr_len : c.chunk_len, c.n_out, b->post);
     WH_LAUNCH_CHECK();
     return WH_OK;
 }

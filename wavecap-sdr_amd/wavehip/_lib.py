@@ -61,6 +61,9 @@ class ChanBankCfg(C.Structure):
         ("n_out", c_int),
         ("pll_alpha", c_double),
         ("pll_beta", c_double),
+        ("noise_reduction", c_int),
+        ("nr_reduction_linear", c_float),
+        ("h_nr_window", C.POINTER(c_float)),
     ]
 
 

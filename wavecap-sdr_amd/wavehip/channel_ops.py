@@ -15,7 +15,7 @@ identical.
 signature and error convention (non-finite input or audio failing validate_audio_samples ->
 (None, metrics); capture.py:323-325, 433-435).  Supported modes: "nbfm", "wbfm", "am", "ssb", "sam"
 with their filter flags, "raw" (mixed IQ, interleaved) and the digital voice modes (metrics only,
-capture.py:424-430).  Spectral noise reduction raises NotImplementedError -- the integration stub keeps routing those to the reference implementation
+capture.py:424-430).  Unknown modes raise NotImplementedError -- the integration stub keeps routing those to the reference implementation
 (INTEGRATION.md); nothing here falls back to a CPU path.
 """
 
@@ -35,6 +35,7 @@ from . import _lib
 logger = logging.getLogger(__name__)
 
 AUDIO_MAX_ABS = 1.2  # validation.py:9
+NR_FFT_SIZE = 1024   # dsp/filters.py:350
 
 
 @dataclass
@@ -68,6 +69,7 @@ class ChannelConfig:
     agc_target_db: float = -20.0
     notch_frequencies: list = field(default_factory=list)
     enable_noise_reduction: bool = False
+    noise_reduction_db: float = 12.0
     sam_sideband: str = "dsb"
     sam_pll_bandwidth_hz: float = 50.0
 
@@ -86,8 +88,6 @@ def resample_design(in_rate: int, out_rate: int):
 def _unsupported(cfg) -> str | None:
     if cfg.mode not in ("nbfm", "wbfm", "am", "ssb", "sam"):
         return f"mode {cfg.mode!r}"
-    if getattr(cfg, "enable_noise_reduction", False) and cfg.mode in ("nbfm", "wbfm"):
-        return "spectral noise reduction"
     return None
 
 
@@ -203,7 +203,8 @@ def _chain_key(cfg):
             float(cfg.am_lowpass_hz), bool(cfg.enable_ssb_bandpass), float(cfg.ssb_bandpass_low_hz),
             float(cfg.ssb_bandpass_high_hz), str(cfg.ssb_mode), float(cfg.ssb_bfo_offset_hz),
             bool(cfg.enable_agc), float(cfg.agc_target_db), tuple(getattr(cfg, "notch_frequencies", None) or ()),
-            str(getattr(cfg, "sam_sideband", "dsb")).lower(), float(getattr(cfg, "sam_pll_bandwidth_hz", 50.0)))
+            str(getattr(cfg, "sam_sideband", "dsb")).lower(), float(getattr(cfg, "sam_pll_bandwidth_hz", 50.0)),
+            bool(getattr(cfg, "enable_noise_reduction", False)), float(getattr(cfg, "noise_reduction_db", 12.0)))
 
 
 class ChannelBank:
@@ -248,9 +249,21 @@ class ChannelBank:
         if agc is not None:
             (cfg.agc_target, cfg.agc_max_gain, cfg.agc_att_b0, cfg.agc_att_a1, cfg.agc_rel_b0,
              cfg.agc_rel_a1) = (float(v) for v in agc)
+        n_fm = self.chunk_len
+        if self.mode in ("nbfm", "wbfm") and getattr(c0, "enable_noise_reduction", False):
+            # dsp/filters.py:346-460 between the filters and rms_normalize (dsp/fm.py:303-304, 399-400); the row
+            # comes back (n_frames-1)*512 + 1024 samples long
+            cfg.noise_reduction = 1
+            cfg.nr_reduction_linear = float(np.float32(10 ** (float(getattr(c0, "noise_reduction_db", 12.0)) / 20.0)))
+            win = np.ascontiguousarray(signal.windows.hann(NR_FFT_SIZE, sym=False).astype(np.float32))
+            cfg.h_nr_window = _lib.dptr(win, "f32")
+            keep.append(win)
+            if n_fm >= NR_FFT_SIZE:
+                n_fm = ((n_fm - NR_FFT_SIZE) // (NR_FFT_SIZE // 2)) * (NR_FFT_SIZE // 2) + NR_FFT_SIZE
+        self.n_fm = n_fm
         if self.sample_rate == self.audio_rate:         # dsp/fm.py:198-199: no resampling
             self.up = self.down = 1
-            self.n_out = self.chunk_len
+            self.n_out = n_fm
             cfg.ntaps = 0
             cfg.up = cfg.down = 1
             cfg.d0 = 0
@@ -258,7 +271,7 @@ class ChannelBank:
             h, up, down, d0 = resample_design(self.sample_rate, self.audio_rate)
             keep.append(h)
             self.up, self.down = up, down
-            n_up = self.chunk_len * up
+            n_up = n_fm * up
             self.n_out = n_up // down + (1 if n_up % down else 0)
             cfg.h_taps = _lib.dptr(h, "f64")
             cfg.ntaps, cfg.up, cfg.down, cfg.d0 = len(h), up, down, d0
