@@ -118,6 +118,8 @@ typedef struct wh_chanbank_cfg {
                                ((N-1024)/512)*512 + 1024 samples and n_out must be computed from that length */
     float nr_reduction_linear;      /* float32(10^(noise_reduction_db/20)) */
     const float *h_nr_window;       /* float32[1024] scipy.signal.windows.hann(1024, sym=False) */
+    const float *h_squelch_db;      /* optional float32[n_channels] (NaN = none): audio of a chunk whose rssi_db is below
+                                       the channel's threshold is zeroed (capture.py:2918-2921); metrics unaffected */
 } wh_chanbank_cfg;
 int wh_chanbank_create(wh_chanbank **out, const wh_chanbank_cfg *cfg);
 int wh_chanbank_run(wh_chanbank *b, const void *d_in, size_t n_chunks, float *d_audio, float *d_metrics,

@@ -535,3 +535,24 @@ def test_chain_spectral_noise_reduction(wh, golden):
         err = np.abs(audio - ref) / np.max(np.abs(ref))
         assert err[8:-8].max() <= TOL and err.max() <= 1e-3, (tag, err[8:-8].max(), err.max())
         assert np.abs(np.array([met["rssi_db"], met["signal_power_db"]]) - g[f"{tag}_met"]).max() <= 2e-4, tag
+
+
+def test_n1_squelch_in_bank(wh):
+    """capture.py:2918-2921 fused into the bank: a channel whose rssi_db is below its squelch_db returns zeros
+    (metrics untouched); channels without a threshold or above it are unchanged."""
+    fs, n = 2400000, 120000
+    offs = S.nbfm_bank_offsets()
+    iq = S.nbfm_bank_c64(n, fs, seed=580)
+    base = [_nbfm_cfg(wh, offs[k]) for k in (3, 13, 20)]
+    plain = wh.ChannelBank(fs, n, base).process(iq)
+    sq = [_nbfm_cfg(wh, offs[k]) for k in (3, 13, 20)]
+    sq[0].squelch_db = plain[0][1]["rssi_db"] + 1.0      # above the measured RSSI -> muted
+    sq[1].squelch_db = plain[1][1]["rssi_db"] - 1.0      # below -> open
+    got = wh.ChannelBank(fs, n, sq, apply_squelch=True).process(iq)
+    assert np.all(got[0][0] == 0) and got[0][0].shape == plain[0][0].shape
+    assert np.array_equal(got[1][0], plain[1][0]) and np.array_equal(got[2][0], plain[2][0])
+    for a, b in zip(got, plain):
+        assert a[1] == b[1]
+    # without apply_squelch the thresholds are ignored (drop-in for the stateless operator)
+    again = wh.ChannelBank(fs, n, sq).process(iq)
+    assert np.array_equal(again[0][0], plain[0][0])

@@ -418,7 +418,8 @@ __global__ __launch_bounds__(64) void chan_rows_kernel(float *rows, double *acc,
 // finalize.  post 0 (FM): scale by 0.18/rms (dsp/fm.py:42-62) + soft clip x0.95 (fm.py:26-39);
 // post 1 (AM/SSB with AGC): audio as is;  post 2 (AM/SSB without AGC): agc.soft_clip (agc.py:58-70)
 __global__ __launch_bounds__(256) void fmbank_finalize_kernel(float *audio, const double *acc, float *metrics,
-                                                              int N, int n_fm, int n_out, int post) {
+                                                              int N, int n_fm, int n_out, int post,
+                                                              const float *squelch_db, int K) {
     const size_t row = blockIdx.x;
     float *au = audio + row * n_out;
     const double *ac = acc + row * 2;
@@ -462,6 +463,15 @@ __global__ __launch_bounds__(256) void fmbank_finalize_kernel(float *audio, cons
         m[1] = (float)(10.0 * log10((double)(p / (float)n_out) + 1e-10));
         m[2] = mx;
         m[3] = bad ? 0.f : 1.f;
+    }
+    // squelch (capture.py:2918-2921): rssi below the channel's threshold -> zeros (metrics keep the unsquelched power)
+    if (squelch_db) {
+        const float sq = squelch_db[row % K];
+        const float rssi = (float)(10.0 * log10(ac[0] / (double)N + 1e-10));
+        if (sq == sq && rssi < sq) {   // NaN = no squelch configured
+            __syncthreads();
+            for (int i = threadIdx.x; i < n_out; i += 256) au[i] = 0.0f;
+        }
     }
 }
 
@@ -715,6 +725,7 @@ __global__ __launch_bounds__(256) void nr_norm_kernel(float *rows, int N, int F,
 struct wh_chanbank {
     wh_chanbank_cfg cfg;
     float *d_nco = nullptr;
+    float *d_squelch = nullptr;
     double *d_taps = nullptr;
     StageDev *d_stages = nullptr;
     double *d_acc = nullptr;
@@ -778,6 +789,11 @@ extern "C" int wh_chanbank_create(wh_chanbank **out, const wh_chanbank_cfg *c) {
     for (int k = 0; k < c->n_channels; ++k) nco[k] = c->h_offsets_hz[k] == 0 ? 0.0f : nco_const(c->h_offsets_hz[k], c->sample_rate);
     WH_HIP(hipMalloc(&b->d_nco, nco.size() * sizeof(float)));
     WH_HIP(hipMemcpy(b->d_nco, nco.data(), nco.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (c->h_squelch_db) {
+        WH_HIP(hipMalloc(&b->d_squelch, (size_t)c->n_channels * sizeof(float)));
+        WH_HIP(hipMemcpy(b->d_squelch, c->h_squelch_db, (size_t)c->n_channels * sizeof(float), hipMemcpyHostToDevice));
+    }
+    b->cfg.h_squelch_db = nullptr;
     if (resample) {
         WH_HIP(hipMalloc(&b->d_taps, (size_t)c->ntaps * sizeof(double)));
         WH_HIP(hipMemcpy(b->d_taps, c->h_taps, (size_t)c->ntaps * sizeof(double), hipMemcpyHostToDevice));
@@ -824,6 +840,7 @@ extern "C" int wh_chanbank_create(wh_chanbank **out, const wh_chanbank_cfg *c) {
 extern "C" void wh_chanbank_destroy(wh_chanbank *b) {
     if (!b) return;
     (void)hipFree(b->d_nco);
+    (void)hipFree(b->d_squelch);
     (void)hipFree(b->d_taps);
     (void)hipFree(b->d_stages);
     (void)hipFree(b->d_acc);
@@ -947,7 +964,7 @@ extern "C" int wh_chanbank_run(wh_chanbank *b, const void *d_in, size_t n_chunks
         }
     }
     hipLaunchKernelGGL(fmbank_finalize_kernel, dim3((unsigned)rows), dim3(256), 0, st, d_audio, b->d_acc, d_metrics,
-                       c.chunk_len, b->nr ? b->nr_len : c.chunk_len, c.n_out, b->post);
+                       c.chunk_len, b->nr ? b->nr_len : c.chunk_len, c.n_out, b->post, b->d_squelch, c.n_channels);
     WH_LAUNCH_CHECK();
     return WH_OK;
 }

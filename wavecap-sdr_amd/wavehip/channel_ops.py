@@ -70,6 +70,7 @@ class ChannelConfig:
     notch_frequencies: list = field(default_factory=list)
     enable_noise_reduction: bool = False
     noise_reduction_db: float = 12.0
+    squelch_db: float | None = None
     sam_sideband: str = "dsb"
     sam_pll_bandwidth_hz: float = 50.0
 
@@ -210,7 +211,11 @@ def _chain_key(cfg):
 class ChannelBank:
     """All channels of one capture that share one chain (mode + filter settings + audio rate)."""
 
-    def __init__(self, sample_rate: int, chunk_len: int, cfgs: list, input_format: str = "cf32"):
+    def __init__(self, sample_rate: int, chunk_len: int, cfgs: list, input_format: str = "cf32",
+                 apply_squelch: bool = False):
+        """apply_squelch=True additionally zeroes the audio of chunks whose rssi_db is below the channel's
+        squelch_db (capture.py:2918-2921; in the reference that happens later, in _apply_stateful_processing,
+        so the drop-in for _process_channel_dsp_stateless leaves it off)."""
         if not cfgs:
             raise ValueError("ChannelBank needs at least one channel")
         for c in cfgs:
@@ -249,6 +254,11 @@ class ChannelBank:
         if agc is not None:
             (cfg.agc_target, cfg.agc_max_gain, cfg.agc_att_b0, cfg.agc_att_a1, cfg.agc_rel_b0,
              cfg.agc_rel_a1) = (float(v) for v in agc)
+        if apply_squelch and any(getattr(c, "squelch_db", None) is not None for c in cfgs):
+            sq = np.array([np.nan if getattr(c, "squelch_db", None) is None else float(c.squelch_db) for c in cfgs],
+                          dtype=np.float32)
+            cfg.h_squelch_db = _lib.dptr(sq, "f32")
+            keep.append(sq)
         n_fm = self.chunk_len
         if self.mode in ("nbfm", "wbfm") and getattr(c0, "enable_noise_reduction", False):
             # dsp/filters.py:346-460 between the filters and rms_normalize (dsp/fm.py:303-304, 399-400); the row
