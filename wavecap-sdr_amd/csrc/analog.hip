@@ -40,6 +40,20 @@ __device__ __forceinline__ float2 mix(float2 x, float c, int n, bool do_mix) {
     return make_float2(x.x * co - x.y * s, x.x * s + x.y * co);
 }
 
+// Same mix for the fused FM bank (tolerance 1e-5, not bit-exact): the float32 phase product is the reference's,
+// its reduction to revolutions uses a two-float product (exact to ~1e-10 rev), then the hardware sin / cos,
+// which take revolutions.  ~13 issue slots instead of ~40.
+__device__ __forceinline__ float2 mix_fast(float2 x, float c, int n) {
+    const float C_HI = 0.15915494f;                 // float32(1 / 2 pi)
+    const float C_LO = 6.4206382e-09f;              // 1 / 2 pi - C_HI
+    float ph = __fmul_rn(c, (float)n);
+    float t_hi = __fmul_rn(ph, C_HI);
+    float t_lo = fmaf(ph, C_LO, fmaf(ph, C_HI, -t_hi));
+    float fr = __builtin_amdgcn_fractf(t_hi) + t_lo;
+    float s = __builtin_amdgcn_sinf(fr), co = __builtin_amdgcn_cosf(fr);
+    return make_float2(fmaf(x.x, co, -(x.y * s)), fmaf(x.x, s, x.y * co));
+}
+
 // atan2f for the analog chains (tolerance 1e-5, no bit-exactness requirement): same octant reduction
 // and minimax polynomial as whm_atan2f, but v_rcp-based quotients instead of IEEE divisions.
 __device__ __forceinline__ float fast_atan2f(float y, float x) {
@@ -154,7 +168,7 @@ struct FmArgs {
     float *fm_out;      // unfused path: [n_chunks][K][N] demodulated rows
     const float *nco_c; // [K] f32(-2 pi off/fs); 0 => no mix
     const double *taps; // [ntaps]
-    int fmt, N, K, n_out, ntaps, down, d0, TO;
+    int fmt, N, K, n_out, ntaps, down, d0, TO, R;   // R: output tiles per workgroup (fused kernel)
     float scale;        // fs / (2 pi 75000)
     int demod;          // 0 FM discriminator, 1 AM envelope, 2 SSB product detector, 3/4/5 SAM dsb/usb/lsb
     double bfo_c;       // 2 pi bfo_hz (SSB), sample_rate in fs_d
@@ -165,56 +179,180 @@ struct FmArgs {
 constexpr int FM_MAX_SPAN = 8192;    // floats of fm kept in LDS (32 KiB -> 4 workgroups per CU)
 constexpr int FM_MAX_TAPS = 2048;    // float64 taps kept in LDS (16 KiB)
 
-__global__ __launch_bounds__(256) void fmbank_fused_kernel(FmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float *taps_s = reinterpret_cast<float *>(smem_raw);                       // taps rounded to float32
-    float *fm_s = reinterpret_cast<float *>(smem_raw + (size_t)a.ntaps * sizeof(float));
-    __shared__ double red[8];
-
-    const int tile = blockIdx.x, k = blockIdx.y, chunk = blockIdx.z;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int N = a.N;
-    const int m0 = tile * a.TO;
-    int mcnt = a.n_out - m0;
-    if (mcnt > a.TO) mcnt = a.TO;
-    const int n_lo = m0 * a.down + a.d0 - (a.ntaps - 1);
-    const int span = a.ntaps + (mcnt - 1) * a.down;
-    const int own_lo = m0 * a.down;
-    int own_hi = (m0 + a.TO) * a.down;  // exclusive
-    if (own_hi > N || m0 + a.TO >= a.n_out) own_hi = N;
-
-    for (int j = tid; j < a.ntaps; j += 256) taps_s[j] = (float)a.taps[j];
-
-    const float c = a.nco_c[k];
-    const bool do_mix = c != 0.0f;
-    const size_t in_base = (size_t)chunk * N;
-    float p_base = 0.f, p_fm = 0.f;
-    // phase 1: each wave covers 63 samples per step; lane 0 only supplies x[n-1]
-    for (int s0 = wave * 63; s0 < span; s0 += 4 * 63) {
-        int i = s0 + lane - 1;          // span index (lane 0 -> previous sample)
-        int n = n_lo + i;               // chunk sample index
-        bool valid = (n >= 0) && (n < N);
+// One workgroup walks a RUN of a.R consecutive output tiles of one (chunk, channel) row.  The discriminator
+// output lives in LDS as a window of ntaps + (TO-1)*down samples; after a tile's FIR the window slides by
+// TO*down: its last ntaps-down samples are moved to the front and only the TO*down new ones are computed, so
+// every input sample is mixed / discriminated once per run instead of once per tile that overlaps it.
+template <bool CHECK, int FMT, bool MIX>
+__device__ __forceinline__ void fm_phase1(const FmArgs &a, float *fm_s, int i_lo, int i_hi, int n_lo, int N, float c,
+                                          size_t in_base, int own_lo, int own_hi, int lane, int wave,
+                                          double &p_base, double &p_fm) {
+    // each wave covers 63 samples per step; lane 0 only supplies x[n-1]
+    for (int s0 = i_lo + wave * 63; s0 < i_hi; s0 += 4 * 63) {
+        const int i = s0 + lane - 1;    // window index (lane 0 -> previous sample)
+        const int n = n_lo + i;         // chunk sample index
+        const bool valid = !CHECK || ((n >= 0) && (n < N));
         float2 bse = make_float2(0.f, 0.f);
-        if (valid) bse = mix(load_iq(a.in, a.fmt, in_base + n), c, n, do_mix);
+        if (valid) {
+            bse = load_iq(a.in, FMT, in_base + n);
+            if (MIX) bse = mix_fast(bse, c, n);
+        }
         float2 prv;
         prv.x = __shfl_up(bse.x, 1);
         prv.y = __shfl_up(bse.y, 1);
-        if (lane > 0 && i < span) {
+        if (lane > 0 && i < i_hi) {
             float v = 0.f;
-            if (valid && n >= 1) {
+            if (valid && (!CHECK || n >= 1)) {
                 float re = bse.x * prv.x + bse.y * prv.y;
                 float im = bse.y * prv.x - bse.x * prv.y;
                 v = fast_atan2f(im, re) * a.scale;
             }
             fm_s[i] = v;
-            if (valid && n >= own_lo && n < own_hi) {
-                p_base += bse.x * bse.x + bse.y * bse.y;
-                p_fm += v * v;
+            if (!CHECK || (valid && n >= own_lo && n < own_hi)) {
+                // float64 running sums: the result must not depend on how a row is cut into runs (batch size)
+                p_base += (double)(bse.x * bse.x + bse.y * bse.y);
+                p_fm += (double)(v * v);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void fmbank_fused_kernel(FmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float *taps_s = reinterpret_cast<float *>(smem_raw);                       // taps rounded to float32, reversed
+    float *fm_s = reinterpret_cast<float *>(smem_raw + (size_t)((a.ntaps + 1) & ~1) * sizeof(float));
+    __shared__ double red[8];
+
+    const int run = blockIdx.x, k = blockIdx.y, chunk = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = a.N;
+    const int n_tiles = (a.n_out + a.TO - 1) / a.TO;
+    const int t_lo = run * a.R;
+    int t_hi = t_lo + a.R;
+    if (t_hi > n_tiles) t_hi = n_tiles;
+    const int W = a.ntaps + (a.TO - 1) * a.down;     // window length
+    const int adv = a.TO * a.down;                   // window advance per tile
+    const int keep = W - adv;                        // samples carried over (may be <= 0: then nothing is reused)
+    const int own_lo = t_lo * adv;
+    const int own_hi = t_hi >= n_tiles ? N : t_hi * adv;   // exclusive
+
+    // taps reversed (trev[i] = h[ntaps-1-i]) so that y[o] = sum_i fm_s[o*down + i] * trev[i] walks both arrays
+    // upwards; one zero pad makes the count even for the paired reads
+    const int ntp = (a.ntaps + 1) & ~1;
+    for (int j = tid; j < ntp; j += 256) taps_s[j] = j < a.ntaps ? (float)a.taps[a.ntaps - 1 - j] : 0.0f;
+    if (tid == 0) fm_s[W] = 0.0f;   // partner of the zero tap pad
+
+    const float c = a.nco_c[k];
+    const bool do_mix = c != 0.0f;
+    const size_t in_base = (size_t)chunk * N;
+    double p_base = 0.0, p_fm = 0.0;
+
+    for (int tile = t_lo; tile < t_hi; ++tile) {
+        const int m0 = tile * a.TO;
+        int mcnt = a.n_out - m0;
+        if (mcnt > a.TO) mcnt = a.TO;
+        const int n_lo = m0 * a.down + a.d0 - (a.ntaps - 1);   // chunk index of window slot 0
+        // phase 1: the whole window for the first tile of the run, the new part afterwards
+        const int i_lo = (tile == t_lo || keep <= 0) ? 0 : keep;
+        // interior: every sample this pass touches (incl. the idle lanes of its last 63-sample step) exists and is owned
+        const bool interior = n_lo + i_lo >= (own_lo > 1 ? own_lo : 1) + 1 && n_lo + W <= own_hi && n_lo + W + 64 <= N;
+#define WH_P1(CHK, F, M) fm_phase1<CHK, F, M>(a, fm_s, i_lo, W, n_lo, N, c, in_base, own_lo, own_hi, lane, wave, p_base, p_fm)
+        if (interior) {
+            if (a.fmt == 1) { if (do_mix) WH_P1(false, 1, true); else WH_P1(false, 1, false); }
+            else            { if (do_mix) WH_P1(false, 0, true); else WH_P1(false, 0, false); }
+        } else {
+            if (a.fmt == 1) { if (do_mix) WH_P1(true, 1, true); else WH_P1(true, 1, false); }
+            else            { if (do_mix) WH_P1(true, 0, true); else WH_P1(true, 0, false); }
+        }
+#undef WH_P1
+        __syncthreads();  // window (and, first time, taps) visible
+
+        // phase 2: y[m0+o] = sum_i fm_s[o*down + i] * trev[i].
+        if (a.TO == 128 && (a.down & 1) == 0) {
+            // 8 lanes share 4 outputs: each lane takes a contiguous 1/8 of the (paired) taps for all 4, so a tap pair
+            // is read once per 8 MACs; packed FMAs; float32 partial sums over 32 pairs, added in float64 (error ~3e-7
+            // of the output scale; scipy accumulates in float64).
+            // lane -> (output group og, tap slice sub): a half-wave holds 8 groups x 4 slices and the slice length is
+            // = 1 (mod 32) pairs, so its 32 eight-byte reads fall on float offsets 8*og + 2*sub (mod 64): all 64 LDS
+            // banks exactly once
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            const int og = (wave << 3) | ((lane >> 2) & 7), sub = (lane & 3) | ((lane >> 5) << 2);
+            const int npairs = ntp >> 1;
+            int per = (npairs + 7) >> 3;
+            per += (33 - (per & 31)) & 31;   // round up to 1 (mod 32)
+            int p_lo = sub * per;
+            if (p_lo > npairs) p_lo = npairs;
+            int p_hi = p_lo + per;
+            if (p_hi > npairs) p_hi = npairs;
+            const v2f *tp = reinterpret_cast<const v2f *>(taps_s);
+            const v2f *f0 = reinterpret_cast<const v2f *>(fm_s + (4 * og) * a.down);
+            const int dstep = a.down >> 1;   // output stride in pairs
+            double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+            for (int pb = p_lo; pb < p_hi; pb += 32) {
+                int pe = pb + 32 < p_hi ? pb + 32 : p_hi;
+                v2f s0 = {0.f, 0.f}, s1 = {0.f, 0.f}, s2 = {0.f, 0.f}, s3 = {0.f, 0.f};
+#pragma unroll 4
+                for (int pp = pb; pp < pe; ++pp) {
+                    v2f t = tp[pp];
+                    s0 = __builtin_elementwise_fma(f0[pp], t, s0);
+                    s1 = __builtin_elementwise_fma(f0[pp + dstep], t, s1);
+                    s2 = __builtin_elementwise_fma(f0[pp + 2 * dstep], t, s2);
+                    s3 = __builtin_elementwise_fma(f0[pp + 3 * dstep], t, s3);
+                }
+                acc0 += (double)(s0.x + s0.y);
+                acc1 += (double)(s1.x + s1.y);
+                acc2 += (double)(s2.x + s2.y);
+                acc3 += (double)(s3.x + s3.y);
+            }
+            for (int w = 1; w <= 32; w = (w == 2 ? 32 : w << 1)) {   // slice bits live in lane bits 0, 1 and 5
+                acc0 += __shfl_xor(acc0, w);
+                acc1 += __shfl_xor(acc1, w);
+                acc2 += __shfl_xor(acc2, w);
+                acc3 += __shfl_xor(acc3, w);
+            }
+            if (sub < 4) {
+                const int o = 4 * og + sub;
+                const double v = sub == 0 ? acc0 : (sub == 1 ? acc1 : (sub == 2 ? acc2 : acc3));
+                if (o < mcnt) a.audio[((size_t)chunk * a.K + k) * a.n_out + m0 + o] = (float)v;
+            }
+        } else {
+            // generic: S = 256/TO lanes share one output
+            const int S = 256 / a.TO;
+            const int o = tid / S, sub = tid - o * S;
+            double accv = 0.0;
+            if (o < mcnt) {
+                const float *f = fm_s + o * a.down;
+                for (int j0 = sub; j0 < a.ntaps; j0 += 32 * S) {
+                    float part = 0.f;
+                    int j1 = j0 + 32 * S < a.ntaps ? j0 + 32 * S : a.ntaps;
+                    for (int j = j0; j < j1; j += S) part = fmaf(f[j], taps_s[j], part);
+                    accv += (double)part;
+                }
+            }
+            for (int w = 1; w < S; w <<= 1) accv += __shfl_xor(accv, w);
+            if (o < mcnt && sub == 0) a.audio[((size_t)chunk * a.K + k) * a.n_out + m0 + o] = (float)accv;
+        }
+        if (tile + 1 < t_hi && keep > 0) {   // slide the window
+            __syncthreads();
+            float carry[4];                  // keep <= ntaps <= FM_MAX_TAPS: at most 8 per thread, 4 at a time
+            for (int j0 = 0; j0 < keep; j0 += 4 * 256) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    int j = j0 + u * 256 + tid;
+                    carry[u] = j < keep ? fm_s[adv + j] : 0.f;
+                }
+                __syncthreads();             // source and destination ranges can overlap when keep > adv
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    int j = j0 + u * 256 + tid;
+                    if (j < keep) fm_s[j] = carry[u];
+                }
+                __syncthreads();
             }
         }
     }
     // block-reduce the two power sums (float64) and publish with one atomic pair
-    double db = (double)p_base, df = (double)p_fm;
+    double db = p_base, df = p_fm;
     for (int o = 32; o > 0; o >>= 1) {
         db += __shfl_xor(db, o);
         df += __shfl_xor(df, o);
@@ -223,29 +361,12 @@ __global__ __launch_bounds__(256) void fmbank_fused_kernel(FmArgs a) {
         red[wave] = db;
         red[4 + wave] = df;
     }
-    __syncthreads();  // also makes fm_s / taps_s visible
+    __syncthreads();
     if (tid == 0) {
         double *acc = a.acc + ((size_t)chunk * a.K + k) * 2;
         atomicAdd(acc, red[0] + red[1] + red[2] + red[3]);
         atomicAdd(acc + 1, red[4] + red[5] + red[6] + red[7]);
     }
-    // phase 2: S = 256/TO lanes share one output; y[m] = sum_j h[j] * fm[(m-m0)*down + ntaps-1-j]
-    const int S = 256 / a.TO;
-    const int o = tid / S, sub = tid - o * S;
-    // float32 products summed in float32 over blocks of 32 taps, block sums added in float64
-    // (error ~3e-7 of the output scale; scipy accumulates in float64)
-    double accv = 0.0;
-    if (o < mcnt) {
-        const float *f = fm_s + o * a.down + (a.ntaps - 1);
-        for (int j0 = sub; j0 < a.ntaps; j0 += 32 * S) {
-            float part = 0.f;
-            int j1 = j0 + 32 * S < a.ntaps ? j0 + 32 * S : a.ntaps;
-            for (int j = j0; j < j1; j += S) part = fmaf(f[-j], taps_s[j], part);
-            accv += (double)part;
-        }
-    }
-    for (int w = 1; w < S; w <<= 1) accv += __shfl_xor(accv, w);
-    if (o < mcnt && sub == 0) a.audio[((size_t)chunk * a.K + k) * a.n_out + m0 + o] = (float)accv;
 }
 
 // unfused first stage: NCO mix + demodulator front (FM discriminator / AM envelope / SSB product
@@ -722,6 +843,22 @@ __global__ __launch_bounds__(256) void nr_norm_kernel(float *rows, int N, int F,
     if (threadIdx.x == 0) acc[(size_t)r * 2 + 1] = red[0];
 }
 
+// tiles per workgroup of the fused FM kernel: as long as the launch keeps >= ~4096 workgroups (16 per CU) longer
+// runs only save work (less window overlap recomputed); a single live chunk of a few channels stays at one tile per
+// workgroup.  Tiles are spread evenly over the runs.  WH_FM_RUN overrides (diagnostics).
+static int run_tiles(int tiles, size_t rows) {
+    size_t total = (size_t)tiles * rows;
+    int R = (int)(total / 4096 < 1 ? 1 : (total / 4096 > (size_t)tiles ? (size_t)tiles : total / 4096));
+    if (const char *e = getenv("WH_FM_RUN")) {
+        int v = atoi(e);
+        if (v >= 1) R = v;
+    }
+    if (R > tiles) R = tiles;
+    if (R < 1) R = 1;
+    const int runs = (tiles + R - 1) / R;
+    return (tiles + runs - 1) / runs;
+}
+
 struct wh_chanbank {
     wh_chanbank_cfg cfg;
     float *d_nco = nullptr;
@@ -828,7 +965,7 @@ extern "C" int wh_chanbank_create(wh_chanbank **out, const wh_chanbank_cfg *c) {
         if (c->ntaps + (TO - 1) * c->down <= FM_MAX_SPAN) {
             b->fused = true;
             b->TO = TO;
-            b->smem = (size_t)c->ntaps * sizeof(float) + (size_t)(c->ntaps + (TO - 1) * c->down) * sizeof(float);
+            b->smem = (size_t)((c->ntaps + 1) & ~1) * sizeof(float) + (size_t)(c->ntaps + 1 + (TO - 1) * c->down) * sizeof(float);
             WH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fmbank_fused_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->smem));
         }
@@ -903,6 +1040,7 @@ extern "C" int wh_chanbank_run(wh_chanbank *b, const void *d_in, size_t n_chunks
     a.down = c.down;
     a.d0 = c.d0;
     a.TO = b->TO;
+    a.R = 1;
     a.scale = (float)((double)c.sample_rate / (2.0 * M_PI * 75000.0));
     a.demod = c.demod;
     a.bfo_c = 2.0 * M_PI * c.bfo_hz;   // Python: (2j*np.pi) * offset_hz
@@ -910,8 +1048,11 @@ extern "C" int wh_chanbank_run(wh_chanbank *b, const void *d_in, size_t n_chunks
     a.pll_alpha = c.pll_alpha;
     a.pll_beta = c.pll_beta;
     if (b->fused) {
-        int tiles = (c.n_out + b->TO - 1) / b->TO;
-        hipLaunchKernelGGL(fmbank_fused_kernel, dim3(tiles, c.n_channels, (unsigned)n_chunks), dim3(256), b->smem, st, a);
+        const int tiles = (c.n_out + b->TO - 1) / b->TO;
+        const int R = run_tiles(tiles, rows);
+        a.R = R;
+        hipLaunchKernelGGL(fmbank_fused_kernel, dim3((tiles + R - 1) / R, c.n_channels, (unsigned)n_chunks), dim3(256),
+                           b->smem, st, a);
         WH_LAUNCH_CHECK();
     } else {
         int per_block = 4 * 63 * 16;
@@ -991,7 +1132,7 @@ extern "C" int wh_channel_signal_metrics(const void *d_in, int input_format, siz
     WH_HIP(hipMemsetAsync(d_acc, 0, (size_t)K * 2 * sizeof(double), st));
     FmArgs a;
     a.in = d_in; a.audio = nullptr; a.acc = d_acc; a.fm_out = d_rows; a.nco_c = d_nco; a.taps = nullptr;
-    a.fmt = input_format; a.N = (int)n; a.K = K; a.n_out = 0; a.ntaps = 0; a.down = 1; a.d0 = 0; a.TO = 1;
+    a.fmt = input_format; a.N = (int)n; a.K = K; a.n_out = 0; a.ntaps = 0; a.down = 1; a.d0 = 0; a.TO = 1; a.R = 1;
     a.scale = 0.f; a.demod = 1; a.bfo_c = 0.0; a.fs_d = (double)sample_rate; a.pll_alpha = a.pll_beta = 0.0;
     const int per_block = 4 * 63 * 16;
     hipLaunchKernelGGL(chan_front_kernel, dim3((unsigned)((n + per_block - 1) / per_block), K, 1), dim3(256), 0, st, a);
