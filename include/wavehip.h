@@ -195,6 +195,20 @@ int wh_ddc_run(wh_ddc *d, const float *d_iq, size_t n, double offset_hz, float *
 int wh_ddc_reset(wh_ddc *d);
 void wh_ddc_destroy(wh_ddc *d);
 
+/* Bank form (N3, trunking/system.py:453-656 VoiceRecorder.process_iq + the control monitor): n_channels <= 64
+ * independent front-ends on ONE wideband buffer, each with its own offset, phase index and filter state.
+ * run(): h_offsets_hz float64[n_channels]; h_active (optional) uint8[n_channels], 0 = recorder idle: skipped,
+ * state kept; d_out complex64 [n_channels][out_stride], out_stride >= wh_ddc_bank_out_len(n).
+ * reset(channel): one channel (a recorder reassigned to a new call), or all with channel = -1.          */
+typedef struct wh_ddc_bank wh_ddc_bank;
+int wh_ddc_bank_create(wh_ddc_bank **out, int n_channels, int sample_rate, const double *h_taps1, int ntaps1,
+                       int decim1, const double *h_taps2, int ntaps2, int decim2, int max_samples_per_call);
+size_t wh_ddc_bank_out_len(const wh_ddc_bank *d, size_t n);
+int wh_ddc_bank_run(wh_ddc_bank *d, const float *d_iq, size_t n, const double *h_offsets_hz,
+                    const unsigned char *h_active, float *d_out, size_t out_stride, void *stream);
+int wh_ddc_bank_reset(wh_ddc_bank *d, int channel);
+void wh_ddc_bank_destroy(wh_ddc_bank *d);
+
 /* ---- A13: control-channel scanner measurement, trunking/cc_scanner.py:165-264 --------------
  * For each candidate offset (already round()ed, 0 = no mix): capture.freq_shift ->
  * lfilter(h_taps float64, zero state) -> [::decim] -> h_out[i] = {mean |y|^2, max |y|^2}

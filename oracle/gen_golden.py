@@ -446,6 +446,61 @@ def gen_trunk():
     save("trunk", **out)
 
 
+def gen_recorder():
+    """N3: VoiceRecorder.process_iq front-end (trunking/system.py:453-656) for two recorders on the same 6 MS/s
+    buffer.  The decimated IQ is a local of process_iq, so scipy.signal.lfilter is wrapped while it runs and the
+    stage outputs are taken from the wrapper (stage 2 output [::D2] = decimated_iq)."""
+    from scipy import signal as ss
+    from wavecapsdr.trunking import system as rsys
+
+    fs, n_chunk = 6_000_000, 150_000
+    lens = [n_chunk, n_chunk, 149_987, 77, n_chunk]
+    x = S.c4fm_iq(sum(lens), fs, 1210, snr_db=25.0, freq_offset_hz=412_500.0)[0]
+    x = (x + np.roll(x, 7) * np.exp(-2j * np.pi * 1_237_500.0 * np.arange(x.size) / fs)).astype(np.complex64)
+    recs = []
+    for rid, off in (("r0", 412_500.0), ("r1", -825_000.0)):
+        r = rsys.VoiceRecorder(id=rid, system_id="s")
+        r.setup_decimation_filter(fs, 48000)
+        r.state = "recording"
+        r._voice_channel = object()       # only tested for None before the DSP front-end
+        r.offset_hz = off
+        recs.append(r)
+    out = {"args": np.array([fs, 1210], dtype=np.int64), "lens": np.array(lens, dtype=np.int64),
+           "sha": np.array(S.sha256(x)), "offsets": np.array([r.offset_hz for r in recs]),
+           "factors": np.array([recs[0]._stage1_decim_factor, recs[0]._stage2_decim_factor], dtype=np.int64),
+           "t1": recs[0]._stage1_filter_taps, "t2": recs[0]._stage2_filter_taps}
+    real = ss.lfilter
+    got = {0: [], 1: []}
+    for ri, r in enumerate(recs):
+        pos = 0
+        for ci, ln in enumerate(lens):
+            if ri == 1 and ci == 1:       # recorder 1 idle during chunk 1: skipped, state kept
+                pos += ln
+                continue
+            calls = []
+
+            def spy(b, a, xx, axis=-1, zi=None):
+                res = real(b, a, xx, axis=axis, zi=zi)
+                calls.append(res[0] if zi is not None else res)
+                return res
+
+            ss.lfilter = spy
+            try:
+                try:
+                    r.process_iq(x[pos:pos + ln], fs)
+                except Exception:          # the vocoder hand-off after the front-end has no event loop here
+                    pass
+            finally:
+                ss.lfilter = real
+            pos += ln
+            assert len(calls) >= 2, (ri, ci, len(calls))
+            got[ri].append(np.asarray(calls[1][::r._stage2_decim_factor]).astype(np.complex64))
+    for ri in (0, 1):
+        out[f"r{ri}_out"] = np.concatenate(got[ri])
+        out[f"r{ri}_counts"] = np.array([len(v) for v in got[ri]], dtype=np.int64)
+    save("trunk_recorder", **out)
+
+
 def gen_cqpsk():
     """A12: Phase-2 CQPSK chain (dsp/p25/cqpsk.py) and the standalone GardnerTED."""
     from wavecapsdr.dsp.p25.cqpsk import CQPSKDemodulator as RefCQPSK
@@ -576,7 +631,7 @@ def gen_lsm():
     save("lsm", **out)
 
 
-ALL = dict(nr=gen_nr, sam=gen_sam, rawdig=gen_rawdig, lsm=gen_lsm, framer=gen_framer, cqpsk=gen_cqpsk, trunk=gen_trunk, a1=gen_a1, a2=gen_a2, a3=gen_a3, a6=gen_a6, chain=gen_chain, a7=gen_a7, a8=gen_a8, c4fm=gen_c4fm)
+ALL = dict(recorder=gen_recorder, nr=gen_nr, sam=gen_sam, rawdig=gen_rawdig, lsm=gen_lsm, framer=gen_framer, cqpsk=gen_cqpsk, trunk=gen_trunk, a1=gen_a1, a2=gen_a2, a3=gen_a3, a6=gen_a6, chain=gen_chain, a7=gen_a7, a8=gen_a8, c4fm=gen_c4fm)
 
 if __name__ == "__main__":
     import logging

@@ -645,6 +645,18 @@ def pfb_channel_stats(out: np.ndarray) -> np.ndarray:
 # --------------------------------------------------------------------------
 
 
+def recorder_decimation_plan(sample_rate: int, target_rate: int = 48000):
+    """VoiceRecorder.setup_decimation_filter stage factors (trunking/system.py:453-485)."""
+    total = max(1, sample_rate // target_rate)
+    if total <= 1:
+        return 1, 1
+    if total >= 100:
+        for s1 in [25, 20, 30, 16]:
+            if total % s1 == 0 and total // s1 <= 10:
+                return s1, total // s1
+    return total, 1
+
+
 class TrunkingDDC:
     """trunking/system.py:1392-1466, 1735-1779 with dsp/filters.py:558-646 (scipy fallback path):
     float64-phase NCO continued across calls (index wrapped at one second), each stage

@@ -556,3 +556,37 @@ def test_n1_squelch_in_bank(wh):
     # without apply_squelch the thresholds are ignored (drop-in for the stateless operator)
     again = wh.ChannelBank(fs, n, sq).process(iq)
     assert np.array_equal(again[0][0], plain[0][0])
+
+
+def test_n3_ddc_bank_voice_recorders(wh, golden, O):
+    """TrunkingDDCBank: recorders sharing one 6 MS/s buffer (VoiceRecorder.process_iq, system.py:453-656) vs the
+    reference goldens, incl. an idle chunk for one recorder, ragged calls and a 77-sample call; and every bank
+    channel == the single-channel TrunkingDDC."""
+    from test_oracle_golden import recorder_case
+    g = golden("trunk_recorder")
+    fs, x, lens = recorder_case(g)
+    assert wh.recorder_decimation_plan(fs) == tuple(int(v) for v in g["factors"])
+    offs = [float(v) for v in g["offsets"]] + [0.0, 1_000_000.0]
+    bank = wh.TrunkingDDCBank(4, fs, plan="recorder")
+    assert np.array_equal(bank.stage1_taps, g["t1"]) and np.array_equal(bank.stage2_taps, g["t2"])
+    singles = [wh.TrunkingDDC(fs, bank.stage1_factor, bank.stage2_factor) for _ in offs]
+    pos, outs = 0, [[] for _ in offs]
+    for ci, ln in enumerate(lens):
+        active = [1, 0 if ci == 1 else 1, 1, 1]
+        res = bank.process(x[pos:pos + ln], offs, active)
+        for k in range(4):
+            if active[k]:
+                outs[k].append(res[k])
+                ref = singles[k].process(x[pos:pos + ln], offs[k])
+                assert np.array_equal(res[k], ref), (ci, k)
+            else:
+                assert res[k] is None
+        pos += ln
+    for ri in (0, 1):
+        assert [len(v) for v in outs[ri]] == [int(v) for v in g[f"r{ri}_counts"]]
+        assert peak_rel_err(np.concatenate(outs[ri]), g[f"r{ri}_out"]) <= TOL
+    # reset of one channel = a fresh front-end for that channel only
+    bank.reset(2)
+    res = bank.process(x[:5000], offs)
+    fresh = wh.TrunkingDDC(fs, bank.stage1_factor, bank.stage2_factor).process(x[:5000], offs[2])
+    assert np.array_equal(res[2], fresh)

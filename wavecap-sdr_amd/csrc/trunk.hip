@@ -98,6 +98,87 @@ __global__ __launch_bounds__(256) void ddc_carry_kernel(DdcArgs a, float2 *hist_
     hist_new[i] = v;
 }
 
+
+// ---- bank form of the front-end: K voice recorders / control monitors on ONE wideband buffer -------------
+// (trunking/system.py:453-656 VoiceRecorder.process_iq runs the same NCO + two lfilter/[::D] stages per recorder,
+// each with its own offset, sample index and filter state; inactive recorders are skipped and keep their state.)
+constexpr int DDC_BANK_MAX = 64;
+
+struct DdcChan {
+    double c1;            // (-2.0*np.pi) * offset_hz
+    long long idx0;       // sample index of x[0]
+    int mix, first, active, cur;
+};
+
+struct DdcBankArgs {
+    const float2 *x;      // stage 1: the shared input (x_stride 0); stage 2: [K][x_stride]
+    size_t x_stride;
+    float2 *hist[2];      // [K][L-1] each, double-buffered per channel (DdcChan.cur selects the valid one)
+    float2 *out;          // [K][out_stride]
+    size_t out_stride;
+    const double *taps;
+    int L, D, n, n_out, opw, stage2;
+    double fs;
+    DdcChan ch[DDC_BANK_MAX];
+};
+
+__device__ __forceinline__ float2 ddcb_fetch(const DdcBankArgs &a, const DdcChan &c, const float2 *x, const float2 *hist,
+                                             long long p) {
+    DdcArgs m;            // reuse ddc_mix's arithmetic
+    m.mix = a.stage2 ? 0 : c.mix; m.c1 = c.c1; m.fs = a.fs; m.idx0 = c.idx0;
+    if (p >= 0) return ddc_mix(x[p], m, p);
+    if (c.first) return ddc_mix(x[0], m, 0);
+    return hist[p + (a.L - 1)];
+}
+
+__global__ __launch_bounds__(256) void ddcb_stage_kernel(DdcBankArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm_raw[];
+    const DdcChan &c = a.ch[blockIdx.y];
+    if (!c.active) return;
+    double *tp = reinterpret_cast<double *>(sm_raw);
+    float2 *tile = reinterpret_cast<float2 *>(sm_raw + (size_t)a.L * sizeof(double));
+    const float2 *x = a.x + (size_t)blockIdx.y * a.x_stride;
+    const float2 *hist = a.hist[c.cur] + (size_t)blockIdx.y * (a.L - 1);
+    const int tid = threadIdx.x;
+    const int m0 = blockIdx.x * a.opw;
+    int mc = a.n_out - m0;
+    if (mc > a.opw) mc = a.opw;
+    const int H = a.L - 1;
+    const long long p0 = (long long)m0 * a.D - H;
+    const int span = (mc - 1) * a.D + a.L;
+    for (int i = tid; i < a.L; i += 256) tp[i] = a.taps[i];
+    for (int i = tid; i < span; i += 256) tile[i] = ddcb_fetch(a, c, x, hist, p0 + i);
+    __syncthreads();
+    const int S = 256 / a.opw;
+    const int o = tid / S, sub = tid - o * S;
+    double ar = 0.0, ai = 0.0;
+    if (o < mc) {
+        const float2 *w = tile + o * a.D + H;
+        for (int k = sub; k < a.L; k += S) {
+            float2 v = w[-k];
+            double t = tp[k];
+            ar = fma(t, (double)v.x, ar);
+            ai = fma(t, (double)v.y, ai);
+        }
+    }
+    for (int w = 1; w < S; w <<= 1) {
+        ar += __shfl_xor(ar, w);
+        ai += __shfl_xor(ai, w);
+    }
+    if (o < mc && sub == 0) a.out[(size_t)blockIdx.y * a.out_stride + m0 + o] = make_float2((float)ar, (float)ai);
+}
+
+__global__ __launch_bounds__(256) void ddcb_carry_kernel(DdcBankArgs a) {
+    const DdcChan &c = a.ch[blockIdx.y];
+    if (!c.active) return;
+    const int H = a.L - 1;
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= H) return;
+    const float2 *x = a.x + (size_t)blockIdx.y * a.x_stride;
+    const float2 *hist = a.hist[c.cur] + (size_t)blockIdx.y * H;
+    a.hist[c.cur ^ 1][(size_t)blockIdx.y * H + i] = ddcb_fetch(a, c, x, hist, (long long)a.n - H + i);
+}
+
 // ---- scanner measurement ----------------------------------------------------------------------
 struct ScanArgs {
     const float2 *x;
@@ -354,6 +435,134 @@ extern "C" int wh_ddc_run(wh_ddc *d, const float *d_iq, size_t n, double offset_
     if (mix) {   // system.py:1461-1466
         d->sample_idx += (long long)n;
         if (d->sample_idx >= d->fs) d->sample_idx %= d->fs;
+    }
+    return WH_OK;
+}
+
+// ---- wh_ddc_bank ---------------------------------------------------------------------------------
+struct wh_ddc_bank {
+    int K, fs, L1, D1, L2, D2, max_n;
+    double *d_t1 = nullptr, *d_t2 = nullptr;
+    float2 *d_h1[2] = {nullptr, nullptr}, *d_h2[2] = {nullptr, nullptr};
+    float2 *d_mid = nullptr;
+    size_t mid_stride = 0;
+    struct Chan { bool first = true; long long sample_idx = 0; double last_offset = 0.0; int cur = 0; };
+    std::vector<Chan> ch;
+};
+
+extern "C" int wh_ddc_bank_create(wh_ddc_bank **out, int n_channels, int sample_rate, const double *h_taps1, int n1, int d1,
+                                  const double *h_taps2, int n2, int d2, int max_samples_per_call) {
+    if (!out || !h_taps1 || n_channels < 1 || n_channels > DDC_BANK_MAX || n1 < 2 || d1 < 1 || sample_rate < 1 ||
+        max_samples_per_call < 1 || n1 > 4096 || (d2 > 1 && (!h_taps2 || n2 < 2 || n2 > 4096)))
+        return set_err(WH_E_ARG, "wh_ddc_bank_create: bad arguments (1..%d channels)", DDC_BANK_MAX);
+    wh_ddc_bank *d = new wh_ddc_bank();
+    std::unique_ptr<wh_ddc_bank, void (*)(wh_ddc_bank *)> guard(d, wh_ddc_bank_destroy);  // frees partial state on early return
+    d->K = n_channels; d->fs = sample_rate; d->L1 = n1; d->D1 = d1; d->L2 = d2 > 1 ? n2 : 0; d->D2 = d2 > 1 ? d2 : 1;
+    d->max_n = max_samples_per_call;
+    d->ch.resize(n_channels);
+    WH_HIP(hipMalloc(&d->d_t1, n1 * sizeof(double)));
+    WH_HIP(hipMemcpy(d->d_t1, h_taps1, n1 * sizeof(double), hipMemcpyHostToDevice));
+    for (int i = 0; i < 2; ++i) WH_HIP(hipMalloc(&d->d_h1[i], (size_t)n_channels * (n1 - 1) * sizeof(float2)));
+    if (d->L2) {
+        WH_HIP(hipMalloc(&d->d_t2, n2 * sizeof(double)));
+        WH_HIP(hipMemcpy(d->d_t2, h_taps2, n2 * sizeof(double), hipMemcpyHostToDevice));
+        for (int i = 0; i < 2; ++i) WH_HIP(hipMalloc(&d->d_h2[i], (size_t)n_channels * (n2 - 1) * sizeof(float2)));
+        d->mid_stride = (size_t)max_samples_per_call / d1 + 2;
+        WH_HIP(hipMalloc(&d->d_mid, (size_t)n_channels * d->mid_stride * sizeof(float2)));
+    }
+    *out = guard.release();
+    return WH_OK;
+}
+
+extern "C" void wh_ddc_bank_destroy(wh_ddc_bank *d) {
+    if (!d) return;
+    (void)hipFree(d->d_t1); (void)hipFree(d->d_t2); (void)hipFree(d->d_mid);
+    for (int i = 0; i < 2; ++i) { (void)hipFree(d->d_h1[i]); (void)hipFree(d->d_h2[i]); }
+    delete d;
+}
+
+extern "C" int wh_ddc_bank_reset(wh_ddc_bank *d, int channel) {
+    if (!d || channel < -1 || channel >= d->K) return set_err(WH_E_ARG, "wh_ddc_bank_reset: bad arguments");
+    for (int k = 0; k < d->K; ++k)
+        if (channel < 0 || channel == k) {
+            int cur = d->ch[k].cur;
+            d->ch[k] = wh_ddc_bank::Chan();
+            d->ch[k].cur = cur;
+        }
+    return WH_OK;
+}
+
+extern "C" size_t wh_ddc_bank_out_len(const wh_ddc_bank *d, size_t n) {
+    if (!d || n == 0) return 0;
+    size_t n1 = (n + d->D1 - 1) / d->D1;
+    return (n1 + d->D2 - 1) / d->D2;
+}
+
+static int ddcb_launch(DdcBankArgs &a, int K, hipStream_t st) {
+    a.opw = pick_opw(a.L, a.D);
+    size_t smem = (size_t)a.L * sizeof(double) + (size_t)((a.opw - 1) * a.D + a.L) * sizeof(float2);
+    if (smem > 64 * 1024) return set_err(WH_E_ARG, "ddc bank: decimation %d x %d taps does not fit the LDS tile", a.D, a.L);
+    hipLaunchKernelGGL(ddcb_stage_kernel, dim3((unsigned)((a.n_out + a.opw - 1) / a.opw), K), dim3(256), smem, st, a);
+    WH_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ddcb_carry_kernel, dim3((a.L - 1 + 255) / 256, K), dim3(256), 0, st, a);
+    WH_LAUNCH_CHECK();
+    return WH_OK;
+}
+
+extern "C" int wh_ddc_bank_run(wh_ddc_bank *d, const float *d_iq, size_t n, const double *h_offsets_hz,
+                               const unsigned char *h_active, float *d_out, size_t out_stride, void *stream) {
+    if (!d) return set_err(WH_E_ARG, "wh_ddc_bank_run: null handle");
+    if (n == 0) return WH_OK;
+    if (!d_iq || !d_out || !h_offsets_hz) return set_err(WH_E_ARG, "wh_ddc_bank_run: null buffer");
+    if (n > (size_t)d->max_n) return set_err(WH_E_ARG, "wh_ddc_bank_run: n exceeds max_samples_per_call");
+    if (out_stride < wh_ddc_bank_out_len(d, n)) return set_err(WH_E_ARG, "wh_ddc_bank_run: out_stride too small");
+    hipStream_t st = as_stream(stream);
+    const int n1 = (int)((n + d->D1 - 1) / d->D1);
+    DdcBankArgs a;
+    a.x = reinterpret_cast<const float2 *>(d_iq);
+    a.x_stride = 0;
+    a.hist[0] = d->d_h1[0]; a.hist[1] = d->d_h1[1];
+    a.out = d->L2 ? d->d_mid : reinterpret_cast<float2 *>(d_out);
+    a.out_stride = d->L2 ? d->mid_stride : out_stride;
+    a.taps = d->d_t1; a.L = d->L1; a.D = d->D1; a.n = (int)n; a.n_out = n1; a.stage2 = 0;
+    a.fs = (double)d->fs;
+    for (int k = 0; k < DDC_BANK_MAX; ++k) a.ch[k] = DdcChan{0.0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < d->K; ++k) {
+        wh_ddc_bank::Chan &c = d->ch[k];
+        DdcChan &g = a.ch[k];
+        g.active = (!h_active || h_active[k]) ? 1 : 0;
+        if (!g.active) continue;
+        const double off = h_offsets_hz[k];
+        g.mix = off != 0.0;
+        if (g.mix && off != c.last_offset) {   // system.py:604-606 / 1450-1452
+            c.sample_idx = 0;
+            c.last_offset = off;
+        }
+        g.c1 = (-2.0 * M_PI) * off;
+        g.idx0 = c.sample_idx;
+        g.first = c.first ? 1 : 0;
+        g.cur = c.cur;
+    }
+    int rc = ddcb_launch(a, d->K, st);
+    if (rc != WH_OK) return rc;
+    if (d->L2) {
+        DdcBankArgs b = a;
+        b.x = d->d_mid; b.x_stride = d->mid_stride;
+        b.hist[0] = d->d_h2[0]; b.hist[1] = d->d_h2[1];
+        b.out = reinterpret_cast<float2 *>(d_out); b.out_stride = out_stride;
+        b.taps = d->d_t2; b.L = d->L2; b.D = d->D2; b.n = n1; b.n_out = (n1 + d->D2 - 1) / d->D2; b.stage2 = 1;
+        rc = ddcb_launch(b, d->K, st);
+        if (rc != WH_OK) return rc;
+    }
+    for (int k = 0; k < d->K; ++k) {
+        if (!a.ch[k].active) continue;
+        wh_ddc_bank::Chan &c = d->ch[k];
+        c.cur ^= 1;
+        c.first = false;
+        if (a.ch[k].mix) {   // system.py:609-611 / 1461-1466
+            c.sample_idx += (long long)n;
+            if (c.sample_idx >= d->fs) c.sample_idx %= d->fs;
+        }
     }
     return WH_OK;
 }

@@ -108,6 +108,12 @@ PROTOTYPES = {
     "wh_spectrum_window": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p]),
     "wh_spectrum_post": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "wh_spectrum_destroy": (None, [c_void_p]),
+    "wh_ddc_bank_create": (c_int, [C.POINTER(c_void_p), c_int, c_int, C.POINTER(c_double), c_int, c_int,
+                                   C.POINTER(c_double), c_int, c_int, c_int]),
+    "wh_ddc_bank_out_len": (c_size_t, [c_void_p, c_size_t]),
+    "wh_ddc_bank_run": (c_int, [c_void_p, c_void_p, c_size_t, C.POINTER(c_double), c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wh_ddc_bank_reset": (c_int, [c_void_p, c_int]),
+    "wh_ddc_bank_destroy": (None, [c_void_p]),
     "wh_ddc_create": (c_int, [C.POINTER(c_void_p), c_int, C.POINTER(c_double), c_int, c_int, C.POINTER(c_double),
                               c_int, c_int, c_int]),
     "wh_ddc_out_len": (c_size_t, [c_void_p, c_size_t]),

@@ -39,6 +39,18 @@ def decimation_plan(input_rate: int, target_output_rate: int = 48000) -> tuple[i
     return s1f, s2f
 
 
+def recorder_decimation_plan(sample_rate: int, target_rate: int = 48000) -> tuple[int, int]:
+    """VoiceRecorder.setup_decimation_filter (trunking/system.py:453-485): two stages only from 100:1 up."""
+    total = max(1, sample_rate // target_rate)
+    if total <= 1:
+        return 1, 1
+    if total >= 100:
+        for s1 in [25, 20, 30, 16]:
+            if total % s1 == 0 and total // s1 <= 10:
+                return s1, total // s1
+    return total, 1
+
+
 class TrunkingDDC:
     def __init__(self, sample_rate: int, stage1_factor: int | None = None, stage2_factor: int | None = None,
                  max_samples_per_call: int = 1 << 20):
@@ -86,6 +98,73 @@ class TrunkingDDC:
         if x.size == 0:
             return x
         return self.process_device(self._torch.from_numpy(x).cuda(), offset_hz).cpu().numpy()
+
+
+class TrunkingDDCBank:
+    """n_channels front-ends (NCO + two-stage decimator, each with its own offset, phase index and filter state)
+    on one wideband buffer per call: the voice-recorder pool of trunking/system.py:453-656 plus the control
+    monitor.  plan="recorder" uses VoiceRecorder.setup_decimation_filter's stage factors, plan="control" the
+    control monitor's (system.py:1310-1345); explicit factors override."""
+
+    MAX_CHANNELS = 64
+
+    def __init__(self, n_channels: int, sample_rate: int, plan: str = "recorder", stage1_factor: int | None = None,
+                 stage2_factor: int | None = None, max_samples_per_call: int = 1 << 20):
+        self._torch = _lib.require_gpu()
+        self.n_channels, self.sample_rate = int(n_channels), int(sample_rate)
+        if stage1_factor is None:
+            stage1_factor, stage2_factor = (recorder_decimation_plan if plan == "recorder" else decimation_plan)(
+                self.sample_rate)
+        self.stage1_factor, self.stage2_factor = int(stage1_factor), int(stage2_factor or 1)
+        if self.stage1_factor < 2:
+            raise ValueError("TrunkingDDCBank needs a decimating first stage")
+        self.stage1_taps = signal.firwin(157, 0.8 / self.stage1_factor, window=("kaiser", 7.857))
+        self.stage2_taps = (signal.firwin(73, 0.8 / self.stage2_factor, window=("kaiser", 7.857))
+                            if self.stage2_factor > 1 else np.zeros(2))
+        self.output_rate = self.sample_rate // self.stage1_factor // self.stage2_factor
+        t1 = np.ascontiguousarray(self.stage1_taps, dtype=np.float64)
+        t2 = np.ascontiguousarray(self.stage2_taps, dtype=np.float64)
+        self._h = C.c_void_p()
+        self._destroy = _lib.lib.wh_ddc_bank_destroy
+        _lib.check(_lib.lib.wh_ddc_bank_create(C.byref(self._h), self.n_channels, self.sample_rate, _lib.dptr(t1, "f64"),
+                                               len(t1), self.stage1_factor, _lib.dptr(t2, "f64"), len(t2),
+                                               self.stage2_factor, int(max_samples_per_call)), "wh_ddc_bank_create")
+
+    def __del__(self):
+        h, destroy = getattr(self, "_h", None), getattr(self, "_destroy", None)
+        if h and destroy:
+            destroy(h)
+            self._h = None
+
+    def reset(self, channel: int = -1) -> None:
+        _lib.check(_lib.lib.wh_ddc_bank_reset(self._h, int(channel)), "wh_ddc_bank_reset")
+
+    def out_len(self, n: int) -> int:
+        return int(_lib.lib.wh_ddc_bank_out_len(self._h, n))
+
+    def process_device(self, iq_dev, offsets_hz, active=None):
+        """iq_dev complex64 GPU tensor [n] -> complex64 [n_channels, out_len(n)]; rows of inactive channels are
+        left untouched (uninitialised on first use)."""
+        torch = self._torch
+        assert iq_dev.is_cuda and iq_dev.dtype == torch.complex64 and iq_dev.is_contiguous()
+        n = iq_dev.numel()
+        m = self.out_len(n)
+        out = torch.empty((self.n_channels, m), dtype=torch.complex64, device=iq_dev.device)
+        offs = np.ascontiguousarray(offsets_hz, dtype=np.float64)
+        assert offs.shape == (self.n_channels,)
+        act = None if active is None else np.ascontiguousarray(active, dtype=np.uint8)
+        _lib.check(_lib.lib.wh_ddc_bank_run(self._h, iq_dev.data_ptr(), n, _lib.dptr(offs, "f64"),
+                                            None if act is None else act.ctypes.data, out.data_ptr(), m,
+                                            _lib.stream_ptr(torch)), "wh_ddc_bank_run")
+        return out
+
+    def process(self, iq, offsets_hz, active=None) -> list:
+        """-> per channel: complex64 array, or None for an inactive channel."""
+        x = np.ascontiguousarray(iq, dtype=np.complex64)
+        if x.size == 0:
+            return [x for _ in range(self.n_channels)]
+        out = self.process_device(self._torch.from_numpy(x).cuda(), offsets_hz, active).cpu().numpy()
+        return [out[k] if active is None or active[k] else None for k in range(self.n_channels)]
 
 
 class ScannerMeasure:
