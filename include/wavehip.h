@@ -259,6 +259,11 @@ int wh_cqpsk_bank_run(wh_cqpsk_bank *b, const float *d_iq, size_t n, size_t iq_s
 int wh_cqpsk_bank_reset(wh_cqpsk_bank *b, void *stream);
 void wh_cqpsk_bank_destroy(wh_cqpsk_bank *b);
 
+/* ---- N4: ChannelClassifier.update, channel_classifier.py:100-125 ---------------------------------
+ * d_power_db float32 [n_frames][n_bins] spectrum frames (wh_spectrum_run output) are folded, in frame order, into
+ * d_stats float64 [n_bins][5] = {sum, sum_sq, count, min, max}; initialise a row to {0, 0, 0, +inf, -inf}.  */
+int wh_binstats_update(const float *d_power_db, size_t n_frames, int n_bins, double *d_stats, void *stream);
+
 /* ---- A12 (LSM): P25 Phase-1 CQPSK / linear simulcast demodulator, decoders/p25.py:190-669 -------------
  * Per call and channel: block AGC (:436-455), NCO from the tracked frequency offset (:460-465), 63-tap
  * 'same'-mode low-pass (:468-471; per call, zero-padded edges, float64 once the NCO runs), then the

@@ -501,6 +501,22 @@ def gen_recorder():
     save("trunk_recorder", **out)
 
 
+def gen_classifier():
+    """N4: ChannelClassifier.update / classify (channel_classifier.py:62-238)."""
+    from wavecapsdr.channel_classifier import ChannelClassifier
+
+    p, freqs = S.classifier_frames()
+    cl = ChannelClassifier(min_collection_seconds=0.0)
+    for f in range(p.shape[0]):
+        cl.update(p[f].tolist(), freqs.tolist(), 851_000_000.0, 2_400_000.0)      # capture.py:2395-2404 passes lists
+    st = np.array([[s.sum, s.sum_sq, s.count, s.min_val, s.max_val] for _, s in sorted(cl._bin_stats.items())])
+    res = cl.classify(force=True)
+    kinds = {"control": 0, "voice": 1, "variable": 2, "unknown": 3}
+    save("classifier", sha=np.array(S.sha256(p)), stats=st,
+         chans=np.array([[c.freq_hz, c.power_db, c.std_dev_db, kinds[c.channel_type]] for c in res]),
+         sample_count=np.array(cl.sample_count))
+
+
 def gen_cqpsk():
     """A12: Phase-2 CQPSK chain (dsp/p25/cqpsk.py) and the standalone GardnerTED."""
     from wavecapsdr.dsp.p25.cqpsk import CQPSKDemodulator as RefCQPSK
@@ -631,7 +647,7 @@ def gen_lsm():
     save("lsm", **out)
 
 
-ALL = dict(recorder=gen_recorder, nr=gen_nr, sam=gen_sam, rawdig=gen_rawdig, lsm=gen_lsm, framer=gen_framer, cqpsk=gen_cqpsk, trunk=gen_trunk, a1=gen_a1, a2=gen_a2, a3=gen_a3, a6=gen_a6, chain=gen_chain, a7=gen_a7, a8=gen_a8, c4fm=gen_c4fm)
+ALL = dict(classifier=gen_classifier, recorder=gen_recorder, nr=gen_nr, sam=gen_sam, rawdig=gen_rawdig, lsm=gen_lsm, framer=gen_framer, cqpsk=gen_cqpsk, trunk=gen_trunk, a1=gen_a1, a2=gen_a2, a3=gen_a3, a6=gen_a6, chain=gen_chain, a7=gen_a7, a8=gen_a8, c4fm=gen_c4fm)
 
 if __name__ == "__main__":
     import logging

@@ -806,3 +806,52 @@ def pack_f32(samples: np.ndarray) -> bytes:
     if samples.size == 0:
         return b""
     return np.clip(samples.astype(np.float32), -1.0, 1.0).tobytes()
+
+
+# ----------------------------------------------------------------------------------------------
+# N4: ChannelClassifier (reference channel_classifier.py:16-238)
+# ----------------------------------------------------------------------------------------------
+
+
+def binstats_update(stats, frames: np.ndarray) -> np.ndarray:
+    """BinStats.update for every bin (channel_classifier.py:26-33): float64 running sum / sum_sq / count /
+    min / max, frames folded in order.  stats float64 [N, 5] or None."""
+    frames = np.atleast_2d(np.asarray(frames, dtype=np.float32)).astype(np.float64)
+    if stats is None:
+        stats = np.zeros((frames.shape[1], 5))
+        stats[:, 3], stats[:, 4] = np.inf, -np.inf
+    for v in frames:
+        stats[:, 0] += v
+        stats[:, 1] += v * v
+        stats[:, 2] += 1
+        stats[:, 3] = np.minimum(stats[:, 3], v)
+        stats[:, 4] = np.maximum(stats[:, 4], v)
+    return stats
+
+
+def classify_bins(stats: np.ndarray, freqs, center_hz: float, min_samples_per_bin: int = 50,
+                  control_variance_threshold: float = 4.0, voice_variance_threshold: float = 10.0) -> list:
+    """ChannelClassifier.classify (channel_classifier.py:145-227) -> [(freq_hz, power_db, std_dev_db, type)]."""
+    cnt = stats[:, 2]
+    mean = np.where(cnt > 0, stats[:, 0] / np.maximum(cnt, 1), 0.0)
+    var = np.where(cnt < 2, 0.0, stats[:, 1] / np.maximum(cnt, 1) - mean * mean)
+    std = np.sqrt(np.maximum(0.0, var))
+    ok = [i for i in range(len(mean)) if cnt[i] >= min_samples_per_bin]
+    if not ok:
+        return []
+    av = sorted(mean[i] for i in ok)
+    noise = av[int(len(av) * 0.2)]
+    out, visited = [], set()
+    for i in sorted(ok, key=lambda j: mean[j], reverse=True):
+        if i in visited or mean[i] < noise + 10:
+            continue
+        prev_avg = mean[i - 1] if i - 1 >= 0 else -np.inf
+        next_avg = mean[i + 1] if i + 1 < len(mean) else -np.inf
+        if mean[i] <= prev_avg or mean[i] <= next_avg:
+            continue
+        visited.update(range(i - 3, i + 4))
+        kind = ("unknown" if mean[i] < noise + 5 else "control" if std[i] < control_variance_threshold
+                else "voice" if std[i] > voice_variance_threshold else "variable")
+        out.append((center_hz + (float(freqs[i]) if i < len(freqs) else 0.0), float(mean[i]), float(std[i]), kind))
+    out.sort(key=lambda c: c[1], reverse=True)
+    return out

@@ -192,3 +192,22 @@ def dqpsk_iq(n: int, fs: float, seed: int, symbol_rate: float = 12000.0, snr_db:
     sigma = amp * 10 ** (-snr_db / 20.0) / np.sqrt(2.0)
     x = x + sigma * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
     return x.astype(np.complex64), dib
+
+
+# --------------------------------------------------------------------------
+# spectrum frames for the channel classifier (N4)
+# --------------------------------------------------------------------------
+
+def classifier_frames():
+    """Synthetic spectrum frames for the classifier rows: float32 [80, 512] dB, noise at -90, a steady carrier
+    (control), an intermittent one (voice), a fading one (variable) and a shoulder next to the steady one."""
+    rng = np.random.default_rng(1300)
+    F, N = 80, 512
+    p = -90.0 + rng.standard_normal((F, N))
+    p[:, 100] = -40.0 + 0.5 * rng.standard_normal(F)
+    p[:, 101] = -48.0 + 0.5 * rng.standard_normal(F)
+    p[:, 300] = np.where(rng.random(F) < 0.5, -45.0, -92.0) + 0.3 * rng.standard_normal(F)
+    p[:, 400] = -50.0 + 6.0 * np.sin(np.arange(F) / 3.0) + 2.0 * rng.standard_normal(F)
+    p[:, 200] = -82.0 + 0.5 * rng.standard_normal(F)
+    freqs = ((np.arange(N) - N // 2) * (2_400_000 / N)).astype(np.float32)
+    return p.astype(np.float32), freqs

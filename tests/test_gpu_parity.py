@@ -590,3 +590,39 @@ def test_n3_ddc_bank_voice_recorders(wh, golden, O):
     res = bank.process(x[:5000], offs)
     fresh = wh.TrunkingDDC(fs, bank.stage1_factor, bank.stage2_factor).process(x[:5000], offs[2])
     assert np.array_equal(res[2], fresh)
+
+
+def test_n4_channel_classifier(wh, golden):
+    """ChannelClassifier drop-in: bin statistics accumulated on the device are BIT-IDENTICAL to the reference's
+    Python-float BinStats (same float64 additions in the same order), classification equal; input as lists
+    (the reference's call), numpy batches and GPU tensors straight from the spectrum backend."""
+    import torch
+    g = golden("classifier")
+    p, freqs = S.classifier_frames()
+    kinds = {"control": 0, "voice": 1, "variable": 2, "unknown": 3}
+    for mode in ("list", "batch", "tensor"):
+        cl = wh.ChannelClassifier(min_collection_seconds=0.0)
+        if mode == "list":
+            for f in range(p.shape[0]):
+                cl.update(p[f].tolist(), freqs.tolist(), 851_000_000.0, 2_400_000.0)
+        elif mode == "batch":
+            for f in range(0, p.shape[0], 32):
+                cl.update(p[f:f + 32], freqs, 851_000_000.0, 2_400_000.0)
+        else:
+            cl.update(torch.from_numpy(p).cuda(), freqs, 851_000_000.0, 2_400_000.0)
+        assert cl.sample_count == int(g["sample_count"]) and cl.is_ready
+        assert np.array_equal(cl.bin_stats(), g["stats"]), mode
+        res = cl.classify(force=True)
+        got = np.array([[c.freq_hz, c.power_db, c.std_dev_db, kinds[c.channel_type]] for c in res])
+        assert np.array_equal(got, g["chans"]), mode
+    # a parameter change clears the statistics (channel_classifier.py:104-110); reset() too
+    cl.update(p[0], freqs, 852_000_000.0, 2_400_000.0)
+    assert cl.sample_count == 1 and cl.get_status()["center_hz"] == 852_000_000.0
+    cl.reset()
+    assert cl.sample_count == 0 and cl.classify(force=True) == []
+    # end to end: frames from the spectrum backend stay on the device
+    be = wh.HipFFTBackend(512)
+    iq = S.noise_c64(512 * 8, 1301)
+    frames = be.execute_device(torch.from_numpy(iq).cuda(), n_frames=8)
+    cl.update(frames.view(8, 512), freqs, 851_000_000.0, 2_400_000.0)
+    assert cl.sample_count == 8 and cl.bin_stats().shape == (512, 5)

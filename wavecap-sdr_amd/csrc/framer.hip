@@ -78,7 +78,35 @@ __global__ __launch_bounds__(256) void audio_stats_kernel(const float *x, size_t
     }
 }
 
+// ChannelClassifier.update (channel_classifier.py:100-125): per-bin running {sum, sum_sq, count, min, max} over
+// spectrum frames, float64, frames added in order -- the same additions in the same order as the reference's
+// Python-float BinStats, so the accumulators are bit-identical.
+__global__ __launch_bounds__(256) void binstats_kernel(const float *power_db, size_t n_frames, int N, double *stats) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= N) return;
+    double *s = stats + (size_t)b * 5;
+    double sum = s[0], sq = s[1], cnt = s[2], mn = s[3], mx = s[4];
+    for (size_t f = 0; f < n_frames; ++f) {
+        const double v = (double)power_db[f * N + b];
+        sum = __dadd_rn(sum, v);
+        sq = __dadd_rn(sq, __dmul_rn(v, v));
+        cnt += 1.0;
+        if (v < mn) mn = v;
+        if (v > mx) mx = v;
+    }
+    s[0] = sum; s[1] = sq; s[2] = cnt; s[3] = mn; s[4] = mx;
+}
+
 }  // namespace
+
+extern "C" int wh_binstats_update(const float *d_power_db, size_t n_frames, int n_bins, double *d_stats, void *stream) {
+    if (n_frames == 0) return WH_OK;
+    if (!d_power_db || !d_stats || n_bins < 1) return set_err(WH_E_ARG, "wh_binstats_update: bad arguments");
+    hipLaunchKernelGGL(binstats_kernel, dim3((n_bins + 255) / 256), dim3(256), 0, as_stream(stream), d_power_db, n_frames,
+                       n_bins, d_stats);
+    WH_LAUNCH_CHECK();
+    return WH_OK;
+}
 
 extern "C" int wh_audio_stats(const float *d_x, size_t n, float *h_out, void *stream) {
     if (!d_x || !h_out || n == 0) return set_err(WH_E_ARG, "wh_audio_stats: bad arguments");

@@ -22,11 +22,12 @@ from .framer import P25P1SoftSyncDetector, SoftSyncBank  # noqa: F401
 from .c4fm import C4FMBank, C4FMDemodulator, c4fm_demod_simple  # noqa: F401
 from .cqpsk import CQPSKBank, CQPSKDemodulator, GardnerBank, GardnerTED  # noqa: F401
 from .lsm import LSMBank, LSMDemodulator  # noqa: F401
+from .classifier import ChannelClassifier, ClassifiedChannel  # noqa: F401
 from .trunking import (TrunkingDDC, TrunkingDDCBank, ScannerMeasure, decimation_plan,  # noqa: F401
                        recorder_decimation_plan)
 
 __all__ = [
     "PolyphaseChannelizer", "ChannelCalculator", "HipFFTBackend", "FFTResult", "FFTBackend", "is_available",
     "register_with", "ChannelBank", "ChannelConfig", "process_channel_dsp_stateless", "update_signal_metrics", "pack_iq16", "unpack_iq16",
-    "pack_pcm16", "pack_f32", "P25P1SoftSyncDetector", "SoftSyncBank", "C4FMBank", "C4FMDemodulator", "c4fm_demod_simple", "CQPSKBank", "CQPSKDemodulator", "GardnerBank", "GardnerTED", "LSMBank", "LSMDemodulator", "TrunkingDDC", "TrunkingDDCBank", "ScannerMeasure", "decimation_plan", "recorder_decimation_plan",
+    "pack_pcm16", "pack_f32", "P25P1SoftSyncDetector", "SoftSyncBank", "C4FMBank", "C4FMDemodulator", "c4fm_demod_simple", "CQPSKBank", "CQPSKDemodulator", "GardnerBank", "GardnerTED", "LSMBank", "LSMDemodulator", "ChannelClassifier", "ClassifiedChannel", "TrunkingDDC", "TrunkingDDCBank", "ScannerMeasure", "decimation_plan", "recorder_decimation_plan",
 ]
