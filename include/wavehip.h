@@ -244,6 +244,24 @@ void wh_c4fm_bank_destroy(wh_c4fm_bank *b);
 int wh_sync_correlate(const float *d_soft, size_t n, size_t stride, int n_channels, const float *d_hist_in,
                       float *d_hist_out, float *d_scores, void *stream);
 
+/* ---- N2: NID front half, decoders/p25_framer.py:475-617 + dsp/fec/bch.py ----------------------------
+ * wh_sync_positions: indices i with d_scores[i] > threshold (p25_framer.py:493), UNORDERED, *d_count may exceed cap.
+ * wh_nid_extract: for each start, the 33 dibits d_dibits[start .. start+32] minus the status dibit at index 11 ->
+ *   64 bits MSB first -> the 63-bit BCH word in bits 62..0 of d_words (p25_framer.py:587-601); ~0 if out of range.
+ * wh_bch_*: BCH(63,16,23) bounded-distance decode (bch.py:533-638) of n words: h_codewords uint64[65536] = the
+ *   systematic codewords (data in bits 62..47); d_tracked_nac (optional, per word, 0 = none) enables the second
+ *   pass that overwrites the NAC field (bch.py:556-571); d_data[k] = 16-bit NAC|DUID, d_errors[k] = corrected bit
+ *   count or -1.                                                                                           */
+int wh_sync_positions(const float *d_scores, size_t n, float threshold, int32_t *d_positions, size_t cap,
+                      int32_t *d_count, void *stream);
+int wh_nid_extract(const uint8_t *d_dibits, size_t n, const int32_t *d_starts, size_t n_starts, uint64_t *d_words,
+                   void *stream);
+typedef struct wh_bch wh_bch;
+int wh_bch_create(wh_bch **out, const uint64_t *h_codewords);
+int wh_bch_decode(wh_bch *b, const uint64_t *d_words, size_t n, const int32_t *d_tracked_nac, int32_t *d_data,
+                  int32_t *d_errors, void *stream);
+void wh_bch_destroy(wh_bch *b);
+
 /* ---- A12: P25 Phase-2 CQPSK bank, dsp/p25/cqpsk.py:199-350 + dsp/p25/symbol_timing.py -------
  * RRC matched filter (h_rrc float32 = design_rrc_filter_phase2, h_zi = lfilter_zi(rrc, 1.0)),
  * Costas loop (c_kp, c_ki, c_maxf; cqpsk.py:94-119), Mueller-Muller timing (t_kp, t_ki;

@@ -517,6 +517,63 @@ def gen_classifier():
          sample_count=np.array(cl.sample_count))
 
 
+def gen_nid():
+    """N2: bch_decode (dsp/fec/bch.py:533-658) on random words, and the NID events of
+    P25P1MessageFramer.process_batch (decoders/p25_framer.py:471-617) on a synthetic dibit stream."""
+    from wavecapsdr.dsp.fec.bch import bch_decode
+    from wavecapsdr.decoders import p25_framer as rfr
+
+    rng = np.random.default_rng(1410)
+    words, tracked, data, errs = [], [], [], []
+    for k in range(360):
+        d16 = int(rng.integers(0, 1 << 16))
+        cw = S.bch_encode(d16)
+        n_err = int(rng.integers(0, 15)) if k % 6 else int(rng.integers(10, 13))
+        w = cw
+        for f in rng.choice(63, size=n_err, replace=False):
+            w ^= 1 << int(f)
+        if k % 5 == 0:
+            w = int(rng.integers(0, 1 << 63))                       # arbitrary word
+        tn = [0, (d16 >> 4) & 0xFFF, int(rng.integers(1, 0x1000))][k % 3]
+        bits = np.array([(w >> (62 - i)) & 1 for i in range(63)], dtype=np.uint8)
+        dd, ee = bch_decode(bits, tn if tn else None)
+        words.append(w); tracked.append(tn); data.append(dd); errs.append(ee)
+    out = dict(words=np.array(words, dtype=np.uint64), tracked=np.array(tracked, dtype=np.int32),
+               data=np.array(data, dtype=np.int32), errors=np.array(errs, dtype=np.int32))
+    # framer
+    dib, soft, heads = S.nid_stream()
+    fr = rfr.P25P1MessageFramer()
+    fr.start()
+    log = []
+    real = rfr.bch_decode
+
+    def spy(cw, tn=None):
+        r = real(cw, tn)
+        log.append((fr._debug_symbol_count - 1, int(r[0]), int(r[1]), int(tn or 0)))
+        return r
+
+    rfr.bch_decode = spy
+    try:
+        lens = [137, 61, 300, 5, 211]
+        pos, k = 0, 0
+        counts = []
+        while pos < dib.size:
+            ln = lens[k % len(lens)]
+            k += 1
+            try:
+                counts.append(fr.process_batch(soft[pos:pos + ln], dib[pos:pos + ln]))
+            except Exception as e:        # message assembly downstream of the NID is not part of this row
+                counts.append(-1)
+            pos += ln
+    finally:
+        rfr.bch_decode = real
+    out.update(sha=np.array(S.sha256(dib) + S.sha256(soft)), lens=np.array(lens, dtype=np.int64),
+               attempts=np.array(log, dtype=np.int64),                       # (index, data, errors, tracked) per BCH call
+               events=np.array([(i, (d >> 4) & 0xFFF, d & 0xF, e) for i, d, e, _ in log if e >= 0], dtype=np.int64),
+               nid_counts=np.array(counts, dtype=np.int64))
+    save("nid", **out)
+
+
 def gen_cqpsk():
     """A12: Phase-2 CQPSK chain (dsp/p25/cqpsk.py) and the standalone GardnerTED."""
     from wavecapsdr.dsp.p25.cqpsk import CQPSKDemodulator as RefCQPSK
@@ -647,7 +704,7 @@ def gen_lsm():
     save("lsm", **out)
 
 
-ALL = dict(classifier=gen_classifier, recorder=gen_recorder, nr=gen_nr, sam=gen_sam, rawdig=gen_rawdig, lsm=gen_lsm, framer=gen_framer, cqpsk=gen_cqpsk, trunk=gen_trunk, a1=gen_a1, a2=gen_a2, a3=gen_a3, a6=gen_a6, chain=gen_chain, a7=gen_a7, a8=gen_a8, c4fm=gen_c4fm)
+ALL = dict(nid=gen_nid, classifier=gen_classifier, recorder=gen_recorder, nr=gen_nr, sam=gen_sam, rawdig=gen_rawdig, lsm=gen_lsm, framer=gen_framer, cqpsk=gen_cqpsk, trunk=gen_trunk, a1=gen_a1, a2=gen_a2, a3=gen_a3, a6=gen_a6, chain=gen_chain, a7=gen_a7, a8=gen_a8, c4fm=gen_c4fm)
 
 if __name__ == "__main__":
     import logging

@@ -855,3 +855,102 @@ def classify_bins(stats: np.ndarray, freqs, center_hz: float, min_samples_per_bi
         out.append((center_hz + (float(freqs[i]) if i < len(freqs) else 0.0), float(mean[i]), float(std[i]), kind))
     out.sort(key=lambda c: c[1], reverse=True)
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# N2: BCH(63,16,23) NID decode (reference dsp/fec/bch.py) and the framer's NID front half
+# (decoders/p25_framer.py:471-617, decoders/nac_tracker.py)
+# ----------------------------------------------------------------------------------------------
+
+_BCH_TABLE = None
+
+
+def bch_table() -> np.ndarray:
+    """All 65536 systematic codewords, built from the generator matrix: row i = codeword of the unit word 2^i
+    (x^(47+i) plus its remainder modulo g(x) = 0o6331141367235453), the rest by linearity."""
+    global _BCH_TABLE
+    if _BCH_TABLE is None:
+        g = 0o6331141367235453
+        rows = []
+        for i in range(16):
+            r = 1 << (47 + i)
+            for bit in range(62, 46, -1):
+                if (r >> bit) & 1:
+                    r ^= g << (bit - 47)
+            rows.append((1 << (47 + i)) | r)
+        t = np.zeros(1 << 16, dtype=np.uint64)
+        for i, row in enumerate(rows):
+            t[1 << i:1 << (i + 1)] = t[:1 << i] ^ np.uint64(row)
+        _BCH_TABLE = t
+    return _BCH_TABLE
+
+
+def _popcount64(x: np.ndarray) -> np.ndarray:
+    x = x - ((x >> np.uint64(1)) & np.uint64(0x5555555555555555))
+    x = (x & np.uint64(0x3333333333333333)) + ((x >> np.uint64(2)) & np.uint64(0x3333333333333333))
+    x = (x + (x >> np.uint64(4))) & np.uint64(0x0F0F0F0F0F0F0F0F)
+    return (x * np.uint64(0x0101010101010101)) >> np.uint64(56)
+
+
+def bch_decode(word: int, tracked_nac: int = 0):
+    """bch.py:533-638 as a bounded-distance decoder (t = 11, d_min = 23): nearest codeword within 11 bits, else the
+    same search with the tracked NAC written over the first 12 bits, else (0, -1)."""
+    def near(w):
+        d = _popcount64(bch_table() ^ np.uint64(w))
+        i = int(np.argmin(d))
+        return (i, int(d[i])) if d[i] <= 11 else (0, -1)
+    word &= (1 << 63) - 1
+    dat, e = near(word)
+    if e < 0 and tracked_nac and ((word >> 51) & 0xFFF) != tracked_nac:
+        dat, e = near((word & ((1 << 51) - 1)) | (tracked_nac << 51))
+    return dat, e
+
+
+class NIDFrontEnd:
+    """process_batch's NID part: sync positions (score > 60) restart a 33-dibit collection that begins AT the dibit
+    completing the sync; status dibit 11 dropped; BCH; NAC tracker (3 entries, dominant after 3 observations)."""
+
+    def __init__(self):
+        self.sync = SoftSyncDetector()
+        self.buf = None
+        self.count, self.seen, self.tick = {}, {}, 0
+        self.pos = 0
+
+    def tracked(self):
+        if not self.count:
+            return 0
+        nac = max(self.count, key=lambda k: self.count[k])
+        return nac if self.count[nac] >= 3 else 0
+
+    def track(self, nac):
+        self.tick += 1
+        if nac in self.count:
+            self.count[nac] += 1
+        else:
+            self.count[nac] = 1
+        self.seen[nac] = self.tick
+        if len(self.count) > 3:
+            old = min(self.seen, key=lambda k: self.seen[k])
+            del self.count[old], self.seen[old]
+
+    def process_batch(self, soft, dibits):
+        scores = self.sync.process_batch(soft)
+        events = []
+        for i, d in enumerate(np.asarray(dibits, dtype=np.uint8)):
+            if scores[i] > 60.0:
+                self.buf = []
+            if self.buf is not None:
+                self.buf.append(int(d))
+                if len(self.buf) >= 33:
+                    nid = self.buf[:11] + self.buf[12:33]
+                    word = 0
+                    for v in nid:
+                        word = (word << 2) | (v & 3)
+                    dat, e = bch_decode(word >> 1, self.tracked())
+                    self.buf = None
+                    if e >= 0:
+                        nac = (dat >> 4) & 0xFFF
+                        self.track(nac)
+                        events.append((self.pos + i, nac, dat & 0xF, e))
+        self.pos += len(dibits)
+        return events

@@ -211,3 +211,79 @@ def classifier_frames():
     p[:, 200] = -82.0 + 0.5 * rng.standard_normal(F)
     freqs = ((np.arange(N) - N // 2) * (2_400_000 / N)).astype(np.float32)
     return p.astype(np.float32), freqs
+
+
+# --------------------------------------------------------------------------
+# dibit streams for the NID front half (N2)
+# --------------------------------------------------------------------------
+
+BCH_GENERATOR = 0o6331141367235453
+
+
+def bch_encode(data16: int) -> int:
+    """Systematic BCH(63,16,23) codeword (63 bits, data in bits 62..47) of a 16-bit NAC|DUID word."""
+    r = data16 << 47
+    for bit in range(62, 46, -1):
+        if (r >> bit) & 1:
+            r ^= BCH_GENERATOR << (bit - 47)
+    return (data16 << 47) | r
+
+
+def nid_stream(seed: int = 1400):
+    """Dibit + soft-symbol stream with P25 frame heads for the framer's batch path.  In batch mode the reference
+    starts the 33-dibit NID collection AT the dibit that completes the sync (p25_framer.py:503-509), so a head that
+    decodes there is: 24 sync dibits whose last one doubles as NID dibit 0, NID dibits 1..10, one status dibit, NID
+    dibits 11..31 ("batch" heads, NAC >= 0xC00 because the last sync dibit is 3).  "standard" heads (NID right after
+    the sync, as on air) are misaligned for that path and fail BCH.  Returns (dibits uint8, soft float32, heads) with
+    heads = [(kind, start index, data16, flipped bit count)]."""
+    rng = np.random.default_rng(seed)
+    sync = p25_sync_dibits()
+    out, heads = [], []
+
+    def gap(k):
+        out.append(rng.integers(0, 4, size=k, dtype=np.uint8))
+
+    def head(kind, data16, n_err=0, nac_err=0, second_sync_at=None):
+        cw = bch_encode(data16)
+        bits = [(cw >> (62 - i)) & 1 for i in range(63)] + [0]
+        flips = set(int(v) for v in rng.choice(np.arange(12, 63), size=n_err, replace=False)) if n_err else set()
+        flips |= set(int(v) for v in rng.choice(np.arange(2, 12), size=nac_err, replace=False)) if nac_err else set()
+        for f in flips:
+            bits[f] ^= 1
+        nid = [(bits[2 * i] << 1) | bits[2 * i + 1] for i in range(32)]
+        start = sum(len(v) for v in out)
+        status = int(rng.integers(0, 4))
+        if kind == "batch":
+            assert nid[0] == 3
+            d = list(sync) + nid[1:11] + [status] + nid[11:]
+        else:
+            d = list(sync) + nid[:11] + [status] + nid[11:]
+        if second_sync_at is not None:
+            d = d[:24 + second_sync_at] + list(sync) + nid[1:11] + [status] + nid[11:]
+        out.append(np.array(d, dtype=np.uint8))
+        heads.append((kind, start, data16, len(flips)))
+
+    nac = 0xC93
+    gap(40)
+    for k in range(4):                                  # clean heads: the tracker locks onto the NAC
+        head("batch", (nac << 4) | (k & 3) * 3)
+        gap(int(rng.integers(60, 140)))
+    head("standard", (0x293 << 4) | 7)
+    gap(90)
+    head("batch", (nac << 4) | 0x7, n_err=5)
+    gap(75)
+    head("batch", (nac << 4) | 0xC, n_err=11)
+    gap(61)
+    head("batch", (nac << 4) | 0x5, n_err=12)           # beyond t: fails
+    gap(88)
+    head("batch", (nac << 4) | 0x3, n_err=6, nac_err=8)  # 14 errors: only the tracked-NAC second pass recovers it
+    gap(70)
+    head("batch", (0xD55 << 4) | 0x0)                   # another NAC: decodes, tracker keeps the dominant one
+    gap(66)
+    head("batch", (nac << 4) | 0xA, second_sync_at=20)  # a second sync 20 dibits into the collection restarts it
+    gap(120)
+    head("batch", (nac << 4) | 0xF, n_err=2)
+    gap(50)
+    dib = np.concatenate(out)
+    soft = (_DIBIT_TO_SYMBOL[dib] + 0.25 * rng.standard_normal(dib.size)).astype(np.float32)
+    return dib, soft, heads

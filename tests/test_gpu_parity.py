@@ -626,3 +626,57 @@ def test_n4_channel_classifier(wh, golden):
     frames = be.execute_device(torch.from_numpy(iq).cuda(), n_frames=8)
     cl.update(frames.view(8, 512), freqs, 851_000_000.0, 2_400_000.0)
     assert cl.sample_count == 8 and cl.bin_stats().shape == (512, 5)
+
+
+def test_n2_bch_decoder(wh, golden):
+    """Exhaustive nearest-codeword BCH(63,16,23) on the device == the reference's bch_decode, bit for bit:
+    360 golden words (0..14 errors, arbitrary words, tracked-NAC second pass) + the drop-in signature."""
+    g = golden("nid")
+    dec = wh.BCHDecoder()
+    d, e = dec.decode_batch(g["words"], g["tracked"])
+    assert np.array_equal(d, g["data"]) and np.array_equal(e, g["errors"])
+    d0, e0 = dec.decode_batch(g["words"])                       # no tracked NAC: only first-pass results
+    first = g["tracked"] == 0
+    assert np.array_equal(d0[first], g["data"][first]) and np.array_equal(e0[first], g["errors"][first])
+    w = int(g["words"][3])
+    bits = np.array([(w >> (62 - i)) & 1 for i in range(63)], dtype=np.uint8)
+    assert wh.bch_decode(bits, int(g["tracked"][3]) or None) == (int(g["data"][3]), int(g["errors"][3]))
+    assert wh.bch_decode(np.zeros(63, dtype=np.uint8)) == (0, 0)            # reference tests/test_p25_bch.py:38-45
+    for pos in range(63):                                                   # tests/test_reference_fec.py:212-231
+        c = np.zeros(63, dtype=np.uint8)
+        c[pos] = 1
+        assert wh.bch_decode(c) == (0, 1)
+    assert wh.bch_decode(np.zeros(10, dtype=np.uint8)) == (0, -1)
+    # every codeword decodes to itself; 11 errors are corrected, 12 are not mis-corrected to the sent word
+    from wavehip.fec import codeword_table
+    t = codeword_table()
+    rng = np.random.default_rng(1420)
+    idx = rng.integers(0, 1 << 16, size=512)
+    words = t[idx].copy()
+    d, e = dec.decode_batch(words)
+    assert np.array_equal(d, idx.astype(np.int32)) and not e.any()
+    for k in range(512):
+        for f in rng.choice(63, size=11, replace=False):
+            words[k] ^= np.uint64(1) << np.uint64(int(f))
+    d, e = dec.decode_batch(words)
+    assert np.array_equal(d, idx.astype(np.int32)) and np.all(e == 11)
+
+
+def test_n2_nid_front_end(wh, golden):
+    """P25NIDFrontEnd == the NID events of the reference framer's process_batch (same ragged calls), and the events
+    do not depend on how the stream is cut into calls."""
+    g = golden("nid")
+    dib, soft, heads = S.nid_stream()
+    lens = [int(v) for v in g["lens"]]
+    for cut in (lens, [97], [dib.size], [1000, 13]):
+        fe = wh.P25NIDFrontEnd()
+        ev, pos, k = [], 0, 0
+        while pos < dib.size:
+            ln = cut[k % len(cut)]
+            k += 1
+            ev += fe.process_batch(soft[pos:pos + ln], dib[pos:pos + ln])
+            pos += ln
+        assert np.array_equal(np.array(ev, dtype=np.int64), g["events"]), cut
+    assert fe.nac_tracker.get_tracked_nac() == 0xC93
+    fe.reset()
+    assert fe.process_batch(soft[:300], dib[:300]) == [tuple(int(v) for v in r) for r in g["events"] if r[0] < 300]

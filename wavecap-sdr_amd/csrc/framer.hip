@@ -4,6 +4,7 @@
 //       24 symbols; banked over channels.
 //   N4  pack_f32 (reference capture.py:134-144): clip to [-1, 1] before the float32 wire format.
 #include "wh_common.h"
+#include <memory>
 
 using namespace wh;
 
@@ -97,7 +98,132 @@ __global__ __launch_bounds__(256) void binstats_kernel(const float *power_db, si
     s[0] = sum; s[1] = sq; s[2] = cnt; s[3] = mn; s[4] = mx;
 }
 
+// ---- N2: NID front half (decoders/p25_framer.py:475-617, dsp/fec/bch.py) -------------------------------------
+// positions where the soft sync score exceeds the threshold (p25_framer.py:493), unordered (host sorts)
+__global__ void sync_positions_kernel(const float *scores, int n, float threshold, int32_t *out, int cap, int32_t *count) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (scores[i] > threshold) {
+        int k = atomicAdd(count, 1);
+        if (k < cap) out[k] = i;
+    }
+}
+
+// NID word of the 33 dibits starting at `start` (p25_framer.py:587-597): status dibit at index 11 dropped, 32 dibits ->
+// 64 bits MSB first, the first 63 form the BCH word (bit 62 = first bit).  Starts whose 33 dibits are not all inside
+// [0, n) give ~0 (never a codeword neighbour).
+__global__ void nid_extract_kernel(const uint8_t *dibits, int n, const int32_t *starts, int n_starts, uint64_t *words) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_starts) return;
+    int s0 = starts[k];
+    if (s0 < 0 || s0 + 33 > n) { words[k] = ~0ULL; return; }
+    uint64_t w = 0;
+    for (int j = 0; j < 33; ++j) {
+        if (j == 11) continue;
+        w = (w << 2) | (uint64_t)(dibits[s0 + j] & 3);
+    }
+    words[k] = w >> 1;   // drop the 64th bit
+}
+
+// BCH(63,16,23) bounded-distance decoding by exhaustive nearest-codeword search: d_min = 23, so at most one of the
+// 65536 codewords lies within 11 bit errors of a word -- exactly the words the reference's Berlekamp-Massey / Chien /
+// re-check chain (bch.py:575-638) corrects, with the same (data, error count).  One workgroup per word; pass 2
+// (bch.py:556-571) retries with the tracked NAC written over the first 12 bits.
+__device__ __forceinline__ unsigned bch_search(const uint64_t *cw, uint64_t w, unsigned *red) {
+    unsigned best = 0xffffffffu;   // (distance << 16) | data
+    for (int i = threadIdx.x; i < 65536; i += 256) {
+        unsigned d = (unsigned)__popcll(cw[i] ^ w);
+        unsigned key = (d << 16) | (unsigned)i;
+        best = key < best ? key : best;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned other = __shfl_xor(best, o);
+        best = other < best ? other : best;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
+    __syncthreads();
+    unsigned b = red[0];
+    for (int k = 1; k < 4; ++k) b = red[k] < b ? red[k] : b;
+    return b;
+}
+
+__global__ __launch_bounds__(256) void bch_decode_kernel(const uint64_t *cw, const uint64_t *words, const int32_t *tracked,
+                                                         int32_t *data, int32_t *errors) {
+    __shared__ unsigned red[4];
+    const int k = blockIdx.x;
+    uint64_t w = words[k] & 0x7fffffffffffffffULL;
+    unsigned b = bch_search(cw, w, red);
+    int dat = 0, err = -1;
+    if ((b >> 16) <= 11) { dat = (int)(b & 0xffff); err = (int)(b >> 16); }
+    else {
+        const int tn = tracked ? tracked[k] : 0;
+        const int cur = (int)((w >> 51) & 0xfff);
+        if (tn > 0 && cur != tn) {
+            uint64_t w2 = (w & ((1ULL << 51) - 1)) | ((uint64_t)(tn & 0xfff) << 51);
+            b = bch_search(cw, w2, red);
+            if ((b >> 16) <= 11) { dat = (int)(b & 0xffff); err = (int)(b >> 16); }
+        }
+    }
+    if (threadIdx.x == 0) { data[k] = dat; errors[k] = err; }
+}
+
 }  // namespace
+
+struct wh_bch {
+    uint64_t *d_cw = nullptr;
+};
+
+extern "C" int wh_bch_create(wh_bch **out, const uint64_t *h_codewords) {
+    if (!out || !h_codewords) return set_err(WH_E_ARG, "wh_bch_create: null");
+    wh_bch *b = new wh_bch();
+    std::unique_ptr<wh_bch, void (*)(wh_bch *)> guard(b, wh_bch_destroy);  // frees partial state on early return
+    WH_HIP(hipMalloc(&b->d_cw, 65536 * sizeof(uint64_t)));
+    WH_HIP(hipMemcpy(b->d_cw, h_codewords, 65536 * sizeof(uint64_t), hipMemcpyHostToDevice));
+    *out = guard.release();
+    return WH_OK;
+}
+
+extern "C" void wh_bch_destroy(wh_bch *b) {
+    if (!b) return;
+    (void)hipFree(b->d_cw);
+    delete b;
+}
+
+extern "C" int wh_bch_decode(wh_bch *b, const uint64_t *d_words, size_t n, const int32_t *d_tracked_nac, int32_t *d_data,
+                             int32_t *d_errors, void *stream) {
+    if (!b) return set_err(WH_E_ARG, "wh_bch_decode: null handle");
+    if (n == 0) return WH_OK;
+    if (!d_words || !d_data || !d_errors || n > 0x7fffffff) return set_err(WH_E_ARG, "wh_bch_decode: bad arguments");
+    hipLaunchKernelGGL(bch_decode_kernel, dim3((unsigned)n), dim3(256), 0, as_stream(stream), b->d_cw, d_words,
+                       d_tracked_nac, d_data, d_errors);
+    WH_LAUNCH_CHECK();
+    return WH_OK;
+}
+
+extern "C" int wh_sync_positions(const float *d_scores, size_t n, float threshold, int32_t *d_positions, size_t cap,
+                                 int32_t *d_count, void *stream) {
+    if (!d_scores || !d_positions || !d_count || n > 0x7fffffff || cap > 0x7fffffff)
+        return set_err(WH_E_ARG, "wh_sync_positions: bad arguments");
+    hipStream_t st = as_stream(stream);
+    WH_HIP(hipMemsetAsync(d_count, 0, sizeof(int32_t), st));
+    if (n == 0) return WH_OK;
+    hipLaunchKernelGGL(sync_positions_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scores, (int)n,
+                       threshold, d_positions, (int)cap, d_count);
+    WH_LAUNCH_CHECK();
+    return WH_OK;
+}
+
+extern "C" int wh_nid_extract(const uint8_t *d_dibits, size_t n, const int32_t *d_starts, size_t n_starts,
+                              uint64_t *d_words, void *stream) {
+    if (n_starts == 0) return WH_OK;
+    if (!d_dibits || !d_starts || !d_words || n > 0x7fffffff || n_starts > 0x7fffffff)
+        return set_err(WH_E_ARG, "wh_nid_extract: bad arguments");
+    hipLaunchKernelGGL(nid_extract_kernel, dim3((unsigned)((n_starts + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       d_dibits, (int)n, d_starts, (int)n_starts, d_words);
+    WH_LAUNCH_CHECK();
+    return WH_OK;
+}
 
 extern "C" int wh_binstats_update(const float *d_power_db, size_t n_frames, int n_bins, double *d_stats, void *stream) {
     if (n_frames == 0) return WH_OK;

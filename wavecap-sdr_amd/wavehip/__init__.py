@@ -18,7 +18,8 @@ from .fft_backend import HipFFTBackend, FFTResult, FFTBackend, is_available, reg
 from .channel_ops import (ChannelBank, ChannelConfig, process_channel_dsp_stateless,  # noqa: F401
                           update_signal_metrics)
 from .wire import pack_iq16, unpack_iq16, pack_pcm16, pack_f32  # noqa: F401
-from .framer import P25P1SoftSyncDetector, SoftSyncBank  # noqa: F401
+from .framer import P25P1SoftSyncDetector, SoftSyncBank, P25NIDFrontEnd, NACTracker  # noqa: F401
+from .fec import BCHDecoder, bch_decode  # noqa: F401
 from .c4fm import C4FMBank, C4FMDemodulator, c4fm_demod_simple  # noqa: F401
 from .cqpsk import CQPSKBank, CQPSKDemodulator, GardnerBank, GardnerTED  # noqa: F401
 from .lsm import LSMBank, LSMDemodulator  # noqa: F401
@@ -29,5 +30,5 @@ from .trunking import (TrunkingDDC, TrunkingDDCBank, ScannerMeasure, decimation_
 __all__ = [
     "PolyphaseChannelizer", "ChannelCalculator", "HipFFTBackend", "FFTResult", "FFTBackend", "is_available",
     "register_with", "ChannelBank", "ChannelConfig", "process_channel_dsp_stateless", "update_signal_metrics", "pack_iq16", "unpack_iq16",
-    "pack_pcm16", "pack_f32", "P25P1SoftSyncDetector", "SoftSyncBank", "C4FMBank", "C4FMDemodulator", "c4fm_demod_simple", "CQPSKBank", "CQPSKDemodulator", "GardnerBank", "GardnerTED", "LSMBank", "LSMDemodulator", "ChannelClassifier", "ClassifiedChannel", "TrunkingDDC", "TrunkingDDCBank", "ScannerMeasure", "decimation_plan", "recorder_decimation_plan",
+    "pack_pcm16", "pack_f32", "P25P1SoftSyncDetector", "SoftSyncBank", "P25NIDFrontEnd", "NACTracker", "BCHDecoder", "bch_decode", "C4FMBank", "C4FMDemodulator", "c4fm_demod_simple", "CQPSKBank", "CQPSKDemodulator", "GardnerBank", "GardnerTED", "LSMBank", "LSMDemodulator", "ChannelClassifier", "ClassifiedChannel", "TrunkingDDC", "TrunkingDDCBank", "ScannerMeasure", "decimation_plan", "recorder_decimation_plan",
 ]
