@@ -680,3 +680,30 @@ def test_n2_nid_front_end(wh, golden):
     assert fe.nac_tracker.get_tracked_nac() == 0xC93
     fe.reset()
     assert fe.process_batch(soft[:300], dib[:300]) == [tuple(int(v) for v in r) for r in g["events"] if r[0] < 300]
+
+
+def test_chain_wbfm_time_parallel_iir_equals_sequential(wh, golden, monkeypatch):
+    """The time-parallel form of the IIR rows (64 segments per row, each warmed up over the samples before it; used
+    when the chain has no AGC and its impulse responses die out well inside the chunk) against the strictly
+    sequential recurrence (WH_IIR_SEQ=1): same audio to ~1e-7 of peak (float32 stage rounding noise), both within
+    the tolerance of the reference golden; and the warm-up length the host derives covers the slowest pole."""
+    from wavehip.channel_ops import build_chain, iir_warmup_samples
+    g = golden("chain_analog")
+    fs, n, seed, off = (int(v) for v in g["wbfm1_args"])
+    iq = S.fm_tone_c64(n, fs, seed=seed, carrier_hz=float(off))
+    cfg = wh.ChannelConfig(mode="wbfm", offset_hz=float(off))
+    stages = build_chain(cfg, fs)[2]
+    warm = iir_warmup_samples(stages)
+    assert 2657 < warm < 6000                       # butter(5, 15 kHz @ 2.4 MS/s): slowest pole radius 0.98794
+    par = wh.ChannelBank(fs, n, [cfg]).process(iq)[0][0]
+    monkeypatch.setenv("WH_IIR_SEQ", "1")
+    seq = wh.ChannelBank(fs, n, [cfg]).process(iq)[0][0]
+    monkeypatch.delenv("WH_IIR_SEQ")
+    ref = g["wbfm1_audio"]
+    assert peak_rel_err(par, ref) <= TOL and peak_rel_err(seq, ref) <= TOL
+    assert peak_rel_err(par, seq) <= 1e-6
+    # a chain whose poles are too slow for the chunk (or, in ba form at this rate, numerically on the unit circle)
+    # stays sequential: warm-up 0 ("never") or longer than half the chunk
+    hp = wh.ChannelConfig(mode="nbfm", offset_hz=0.0, enable_deemphasis=False, enable_fm_highpass=True, fm_highpass_hz=300)
+    w = iir_warmup_samples(build_chain(hp, fs)[2])
+    assert w == 0 or w > n // 2

@@ -479,61 +479,161 @@ struct AgcDev {
     float target, max_gain, att_b0, att_a1, rel_b0, rel_a1;
 };
 
-__global__ __launch_bounds__(64) void chan_rows_kernel(float *rows, double *acc, int n_rows, int N,
-                                                      const StageDev *stages, int n_stages, AgcDev agc) {
-    __shared__ StageDev st_s[MAX_STAGES];
-    __shared__ double z_s[MAX_STAGES][MAX_ORD - 1][64];   // filter state, [stage][k][lane]
+struct StageArr {
+    StageDev st[MAX_STAGES];   // by value: the coefficients are wave-uniform and arrive through scalar loads
+};
+
+// One lfilter stage (direct form II transposed, scipy's recurrence) with NC coefficients over the cnt samples of one
+// row held in the LDS tile: coefficients and state in registers, every operation rounded on its own (no FMA), in the
+// stage's dtype; the next sample is fetched from LDS while the current one walks the recurrence.
+constexpr int ROWS_CH = 64;
+
+template <int NC, bool F64>
+__device__ __forceinline__ void iir_run(float (*tile)[65], int cnt, int lane, double (&z)[MAX_ORD - 1], const StageDev &S) {
+    double b[NC], a[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) { b[k] = S.b[k]; a[k] = S.a[k]; }
+    float xn = tile[0][lane];
+    for (int j = 0; j < cnt; ++j) {
+        const float x = xn;
+        if (j + 1 < cnt) xn = tile[j + 1][lane];
+        if (F64) {
+            const double xd = (double)x;
+            const double y = __dadd_rn(z[0], __dmul_rn(b[0], xd));
+#pragma unroll
+            for (int k = 0; k < NC - 2; ++k) z[k] = __dsub_rn(__dadd_rn(z[k + 1], __dmul_rn(xd, b[k + 1])), __dmul_rn(y, a[k + 1]));
+            if (NC >= 2) z[NC - 2] = __dsub_rn(__dmul_rn(xd, b[NC - 1]), __dmul_rn(y, a[NC - 1]));
+            tile[j][lane] = (float)y;
+        } else {
+            const float y = __fadd_rn((float)z[0], __fmul_rn((float)b[0], x));
+#pragma unroll
+            for (int k = 0; k < NC - 2; ++k)
+                z[k] = (double)__fsub_rn(__fadd_rn((float)z[k + 1], __fmul_rn(x, (float)b[k + 1])), __fmul_rn(y, (float)a[k + 1]));
+            if (NC >= 2) z[NC - 2] = (double)__fsub_rn(__fmul_rn(x, (float)b[NC - 1]), __fmul_rn(y, (float)a[NC - 1]));
+            tile[j][lane] = y;
+        }
+    }
+}
+
+template <bool F64>
+__device__ __forceinline__ void iir_stage(float (*tile)[65], int cnt, int lane, double (&z)[MAX_ORD - 1], const StageDev &S) {
+    switch (S.n) {   // wave-uniform, once per (tile, stage)
+        case 1: iir_run<1, F64>(tile, cnt, lane, z, S); break;
+        case 2: iir_run<2, F64>(tile, cnt, lane, z, S); break;
+        case 3: iir_run<3, F64>(tile, cnt, lane, z, S); break;
+        case 4: iir_run<4, F64>(tile, cnt, lane, z, S); break;
+        case 5: iir_run<5, F64>(tile, cnt, lane, z, S); break;
+        case 6: iir_run<6, F64>(tile, cnt, lane, z, S); break;
+        case 7: iir_run<7, F64>(tile, cnt, lane, z, S); break;
+        case 8: iir_run<8, F64>(tile, cnt, lane, z, S); break;
+        case 9: iir_run<9, F64>(tile, cnt, lane, z, S); break;
+        case 10: iir_run<10, F64>(tile, cnt, lane, z, S); break;
+        default: iir_run<11, F64>(tile, cnt, lane, z, S); break;
+    }
+}
+
+// One lane per "virtual row"; samples move through an LDS staging tile of ROWS_CH samples x 64 virtual rows: the wave
+// loads it with coalesced 256-byte reads (all 64 lanes on one virtual row at a time), each lane then runs its row
+// through stage after stage (cascading per tile is the same arithmetic as cascading per sample), then the AGC, and the
+// tile is written back coalesced.
+//   seg == 0: a wave owns 64 (chunk, channel) rows, one lane each, zero initial state (the stateless operator).
+//   seg  > 0: TIME-PARALLEL mode for chains whose impulse responses have died out after `warm` samples (the host
+//             derives `warm` from the pole radii, target 1e-14): a wave owns ONE row cut into 64 segments of `seg`
+//             samples; pass A runs every lane over the `warm` samples before its segment (from zero state, nothing
+//             written: the true state differs by < 1e-14 relative), pass B runs it over its segment in place.  64x less
+//             sequential depth for (seg + warm) / seg times the arithmetic.  Not available with the AGC (its release
+//             time constant spans the chunk).
+template <int NS>
+__global__ __launch_bounds__(64) void chan_rows_kernel(float *rows, double *acc, int n_rows, int N, StageArr sa,
+                                                      AgcDev agc, int seg, int warm) {
+    __shared__ float tile[ROWS_CH][65];   // [sample][row], padded: column walks and row walks are both conflict-free
     const int lane = threadIdx.x;
-    for (int i = lane; i < n_stages * (int)(sizeof(StageDev) / 4); i += 64)
-        reinterpret_cast<int *>(st_s)[i] = reinterpret_cast<const int *>(stages)[i];
-    for (int s = 0; s < n_stages; ++s)
-        for (int k = 0; k < MAX_ORD - 1; ++k) z_s[s][k][lane] = 0.0;
-    __syncthreads();
-    const int r = blockIdx.x * 64 + lane;
-    if (r >= n_rows) return;
-    float *f = rows + (size_t)r * N;
+    const int r0 = seg ? blockIdx.x : blockIdx.x * 64;
+    int nr = seg ? (N + seg - 1) / seg : n_rows - r0;   // live lanes (virtual rows)
+    if (nr > 64) nr = 64;
+    double z[NS > 0 ? NS : 1][MAX_ORD - 1];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int k = 0; k < MAX_ORD - 1; ++k) z[s][k] = 0.0;
     float za = 0.f, zr = 0.f;
     const float NORM = (float)(1.0 / 0.90514825364486640);
     double ss = 0.0;
-    for (int i = 0; i < N; ++i) {
-        float x = f[i];
-        for (int s = 0; s < n_stages; ++s) {
-            const StageDev &S = st_s[s];
-            const int n = S.n;
-            if (S.is_f64) {
-                double xd = (double)x;
-                double y = __dadd_rn(z_s[s][0][lane], __dmul_rn(S.b[0], xd));
-                for (int k = 0; k < n - 2; ++k)
-                    z_s[s][k][lane] = __dsub_rn(__dadd_rn(z_s[s][k + 1][lane], __dmul_rn(xd, S.b[k + 1])),
-                                                __dmul_rn(y, S.a[k + 1]));
-                if (n >= 2) z_s[s][n - 2][lane] = __dsub_rn(__dmul_rn(xd, S.b[n - 1]), __dmul_rn(y, S.a[n - 1]));
-                x = (float)y;
-            } else {
-                float y = __fadd_rn((float)z_s[s][0][lane], __fmul_rn((float)S.b[0], x));
-                for (int k = 0; k < n - 2; ++k)
-                    z_s[s][k][lane] = (double)__fsub_rn(__fadd_rn((float)z_s[s][k + 1][lane], __fmul_rn(x, (float)S.b[k + 1])),
-                                                        __fmul_rn(y, (float)S.a[k + 1]));
-                if (n >= 2)
-                    z_s[s][n - 2][lane] = (double)__fsub_rn(__fmul_rn(x, (float)S.b[n - 1]), __fmul_rn(y, (float)S.a[n - 1]));
-                x = y;
+    for (int pass = seg ? 0 : 1; pass < 2; ++pass) {
+        // virtual row l: offset vo(l) into the buffer, length vn(l)
+        auto vo = [&](int l) -> size_t {
+            if (!seg) return (size_t)(r0 + l) * N;
+            const int st = l * seg;
+            return (size_t)r0 * N + (pass == 0 ? st - (st < warm ? st : warm) : st);
+        };
+        auto vn = [&](int l) -> int {
+            if (!seg) return N;
+            const int st = l * seg;
+            if (pass == 0) return st < warm ? st : warm;
+            const int left = N - st;
+            return left < seg ? (left > 0 ? left : 0) : seg;
+        };
+        const int span = seg ? (pass == 0 ? warm : seg) : N;
+        const int my_n = lane < nr ? vn(lane) : 0;
+        for (int i0 = 0; i0 < span; i0 += ROWS_CH) {
+            for (int l0 = 0; l0 < nr; l0 += 16) {   // 16 independent loads in flight before the first LDS write
+                float v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int l = l0 + u;
+                    v[u] = (l < nr && lane < vn(l) - i0) ? rows[vo(l) + i0 + lane] : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (l0 + u < nr) tile[lane][l0 + u] = v[u];
             }
+            __syncthreads();
+            int cnt = my_n - i0;
+            if (cnt > ROWS_CH) cnt = ROWS_CH;
+            if (cnt > 0) {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    if (sa.st[s].is_f64) iir_stage<true>(tile, cnt, lane, z[s], sa.st[s]);
+                    else iir_stage<false>(tile, cnt, lane, z[s], sa.st[s]);
+                }
+                if (agc.on) {
+                    for (int j = 0; j < cnt; ++j) {
+                        float x = tile[j][lane];
+                        float ax = fabsf(x);
+                        float ya = __fadd_rn(za, __fmul_rn(agc.att_b0, ax));
+                        za = __fsub_rn(__fmul_rn(ax, 0.0f), __fmul_rn(ya, agc.att_a1));
+                        float yr = __fadd_rn(zr, __fmul_rn(agc.rel_b0, ya));
+                        zr = __fsub_rn(__fmul_rn(ya, 0.0f), __fmul_rn(yr, agc.rel_a1));
+                        float env = fmaxf(ya, yr);
+                        float g = __fdiv_rn(agc.target, fmaxf(env, (float)1e-6));
+                        g = fminf(g, agc.max_gain);
+                        float y = __fmul_rn(x, g);
+                        x = tanhf(y * 1.5f) * NORM;
+                        tile[j][lane] = x;
+                        ss += (double)x * (double)x;
+                    }
+                } else if (pass == 1) {
+                    for (int j = 0; j < cnt; ++j) {
+                        float x = tile[j][lane];
+                        ss += (double)x * (double)x;
+                    }
+                }
+            }
+            __syncthreads();
+            if (pass == 1)
+                for (int l = 0; l < nr; ++l) {
+                    const int c = vn(l) - i0;
+                    if (lane < c) rows[vo(l) + i0 + lane] = tile[lane][l];
+                }
+            __syncthreads();
         }
-        if (agc.on) {
-            float ax = fabsf(x);
-            float ya = __fadd_rn(za, __fmul_rn(agc.att_b0, ax));
-            za = __fsub_rn(__fmul_rn(ax, 0.0f), __fmul_rn(ya, agc.att_a1));
-            float yr = __fadd_rn(zr, __fmul_rn(agc.rel_b0, ya));
-            zr = __fsub_rn(__fmul_rn(ya, 0.0f), __fmul_rn(yr, agc.rel_a1));
-            float env = fmaxf(ya, yr);
-            float g = __fdiv_rn(agc.target, fmaxf(env, (float)1e-6));
-            g = fminf(g, agc.max_gain);
-            float y = __fmul_rn(x, g);
-            x = tanhf(y * 1.5f) * NORM;
-        }
-        f[i] = x;
-        ss += (double)x * (double)x;
     }
-    acc[(size_t)r * 2 + 1] = ss;
+    if (seg) {
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+        if (lane == 0) acc[(size_t)r0 * 2 + 1] = ss;
+    } else if (lane < nr) {
+        acc[(size_t)(r0 + lane) * 2 + 1] = ss;
+    }
 }
 
 // finalize.  post 0 (FM): scale by 0.18/rms (dsp/fm.py:42-62) + soft clip x0.95 (fm.py:26-39);
@@ -864,7 +964,7 @@ struct wh_chanbank {
     float *d_nco = nullptr;
     float *d_squelch = nullptr;
     double *d_taps = nullptr;
-    StageDev *d_stages = nullptr;
+    StageArr stages{};
     double *d_acc = nullptr;
     float *d_fm = nullptr;
     size_t cap_chunks = 0;
@@ -953,8 +1053,7 @@ extern "C" int wh_chanbank_create(wh_chanbank **out, const wh_chanbank_cfg *c) {
                 }
             }
         }
-        WH_HIP(hipMalloc(&b->d_stages, sd.size() * sizeof(StageDev)));
-        WH_HIP(hipMemcpy(b->d_stages, sd.data(), sd.size() * sizeof(StageDev), hipMemcpyHostToDevice));
+        for (int i = 0; i < c->n_stages; ++i) b->stages.st[i] = sd[i];
     }
     // fused path: plain FM (no IIR stage, no AGC), pure decimation, everything fits in LDS
     b->fused = false;
@@ -979,7 +1078,6 @@ extern "C" void wh_chanbank_destroy(wh_chanbank *b) {
     (void)hipFree(b->d_nco);
     (void)hipFree(b->d_squelch);
     (void)hipFree(b->d_taps);
-    (void)hipFree(b->d_stages);
     (void)hipFree(b->d_acc);
     (void)hipFree(b->d_fm);
     (void)hipFree(b->d_nr_win); (void)hipFree(b->d_nr_tw); (void)hipFree(b->d_nr_mag); (void)hipFree(b->d_nr_sel);
@@ -1069,8 +1167,27 @@ extern "C" int wh_chanbank_run(wh_chanbank *b, const void *d_in, size_t n_chunks
             g.max_gain = c.agc_max_gain;
             g.att_b0 = c.agc_att_b0; g.att_a1 = c.agc_att_a1;
             g.rel_b0 = c.agc_rel_b0; g.rel_a1 = c.agc_rel_a1;
-            hipLaunchKernelGGL(chan_rows_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, st, a.fm_out, b->d_acc,
-                               (int)rows, c.chunk_len, b->d_stages, c.n_stages, g);
+            // time-parallel mode when it at least halves the sequential depth (see chan_rows_kernel)
+            int seg = 0;
+            if (!c.agc && c.iir_warmup > 0 && c.n_stages > 0) {
+                const int sg = (c.chunk_len + 63) / 64;
+                if (sg + c.iir_warmup <= c.chunk_len / 2) seg = sg;
+            }
+            if (getenv("WH_IIR_SEQ")) seg = 0;   // diagnostics: force the sequential form
+            const dim3 rg(seg ? (unsigned)rows : (unsigned)((rows + 63) / 64));
+#define WH_ROWS(NS_) hipLaunchKernelGGL(chan_rows_kernel<NS_>, rg, dim3(64), 0, st, a.fm_out, b->d_acc, (int)rows, c.chunk_len, b->stages, g, seg, c.iir_warmup)
+            switch (c.n_stages) {
+                case 0: WH_ROWS(0); break;
+                case 1: WH_ROWS(1); break;
+                case 2: WH_ROWS(2); break;
+                case 3: WH_ROWS(3); break;
+                case 4: WH_ROWS(4); break;
+                case 5: WH_ROWS(5); break;
+                case 6: WH_ROWS(6); break;
+                case 7: WH_ROWS(7); break;
+                default: WH_ROWS(8); break;
+            }
+#undef WH_ROWS
             WH_LAUNCH_CHECK();
         }
         if (b->nr) {

@@ -64,6 +64,7 @@ class ChanBankCfg(C.Structure):
         ("noise_reduction", c_int),
         ("nr_reduction_linear", c_float),
         ("h_nr_window", C.POINTER(c_float)),
+        ("iir_warmup", c_int),
         ("h_squelch_db", C.POINTER(c_float)),
     ]
 

@@ -189,6 +189,29 @@ def build_chain(cfg, sample_rate: int):
     return demod, float(bfo), stages, agc, post
 
 
+def iir_warmup_samples(stages, tol: float = 1e-14) -> int:
+    """Samples after which the impulse response of every stage of the cascade is below `tol` (relative): from the
+    largest pole radius rho, n = log(tol) / log(rho), padded for the polynomial factor of clustered poles.  0 when a
+    pole sits on / outside the unit circle or the answer is useless (> 2^22)."""
+    rho, order = 0.0, 0
+    for st in stages:
+        a = np.array([st.a[k] for k in range(st.n)], dtype=np.float64)
+        while a.size > 1 and a[-1] == 0.0:
+            a = a[:-1]
+        if a.size > 1:
+            rho = max(rho, float(np.max(np.abs(np.roots(a)))))
+            order += a.size - 1
+    if order == 0:
+        return 1
+    if rho >= 1.0:
+        return 0
+    if rho < 1e-6:
+        return order + 1
+    n = np.log(tol) / np.log(rho)
+    n = 1.25 * n + 32 * order
+    return int(n) if n < (1 << 22) else 0
+
+
 def sam_pll_coefficients(sample_rate: int, loop_bandwidth: float, damping: float = 0.707):
     """dsp/sam.py:55-66 (sample_rate as float, Python-float arithmetic in the reference's order)."""
     fs = float(sample_rate)
@@ -246,6 +269,7 @@ class ChannelBank:
             cfg.pll_alpha, cfg.pll_beta = sam_pll_coefficients(self.sample_rate, float(getattr(c0, "sam_pll_bandwidth_hz", 50.0)))
         keep = [offs]
         cfg.n_stages = len(stages)
+        cfg.iir_warmup = iir_warmup_samples(stages) if (stages and agc is None and demod < 3) else 0
         if stages:
             arr = (_lib.IirStage * len(stages))(*stages)
             cfg.h_stages = arr
