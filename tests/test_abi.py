@@ -40,6 +40,32 @@ def test_argument_errors_do_not_need_a_gpu():
     assert rc == -1 and b"wh_pfb_create" in _lib.lib.wh_last_error()
     rc = _lib.lib.wh_spectrum_create(ctypes.byref(h), 1)
     assert rc == -1
+    # every create() validates its arguments before the first HIP call; a failed create leaves the handle untouched
+    import numpy as np
+    taps = np.ones(8, dtype=np.float64)
+    ftaps = np.ones(63, dtype=np.float32)
+    bad = [
+        ("wh_chanbank_create", lambda: _lib.lib.wh_chanbank_create(ctypes.byref(h), None)),
+        ("wh_lsm_bank_create", lambda: _lib.lib.wh_lsm_bank_create(ctypes.byref(h), 0, 10.0, _lib.dptr(ftaps, "f32"),
+                                                                   _lib.dptr(ftaps, "f32"), 1024)),
+        ("wh_lsm_bank_create", lambda: _lib.lib.wh_lsm_bank_create(ctypes.byref(h), 4, 1.0, _lib.dptr(ftaps, "f32"),
+                                                                   _lib.dptr(ftaps, "f32"), 1024)),
+        ("wh_ddc_bank_create", lambda: _lib.lib.wh_ddc_bank_create(ctypes.byref(h), 65, 2400000, _lib.dptr(taps, "f64"),
+                                                                   8, 10, None, 0, 1, 4096)),
+        ("wh_ddc_create", lambda: _lib.lib.wh_ddc_create(ctypes.byref(h), 0, _lib.dptr(taps, "f64"), 8, 10, None, 0, 1, 4096)),
+        ("wh_bch_create", lambda: _lib.lib.wh_bch_create(ctypes.byref(h), None)),
+        ("wh_resampler_create", lambda: _lib.lib.wh_resampler_create(ctypes.byref(h), None, 0, 1, 1, 0)),
+        ("wh_gardner_bank_create", lambda: _lib.lib.wh_gardner_bank_create(ctypes.byref(h), 0, 10.0, 0.1, 0.01)),
+    ]
+    for name, call in bad:
+        h.value = None
+        assert call() == -1, name
+        assert name.encode() in _lib.lib.wh_last_error(), (name, _lib.lib.wh_last_error())
+        assert not h.value, name
+    # run() on a null handle is an argument error too, not a crash
+    assert _lib.lib.wh_lsm_bank_run(None, None, 16, 16, None, None, 16, None, None) == -1
+    assert _lib.lib.wh_ddc_bank_run(None, None, 16, None, None, None, 16, None) == -1
+    assert _lib.lib.wh_bch_decode(None, None, 1, None, None, None, None) == -1
 
 
 def test_product_has_no_oracle_or_cpu_fallback():
