@@ -707,3 +707,36 @@ def test_chain_wbfm_time_parallel_iir_equals_sequential(wh, golden, monkeypatch)
     hp = wh.ChannelConfig(mode="nbfm", offset_hz=0.0, enable_deemphasis=False, enable_fm_highpass=True, fm_highpass_hz=300)
     w = iir_warmup_samples(build_chain(hp, fs)[2])
     assert w == 0 or w > n // 2
+
+
+def test_n1_channel_dispatcher_mixed_modes(wh, golden):
+    """ChannelDispatcher = the DSP fan-out of Capture._process_channels_parallel (capture.py:2489-2597) in batched
+    form: a mixed channel set (3 NBFM, 1 WBFM, raw, p25, NBFM with another filter set) on one chunk gives, per
+    channel and in order, what process_channel_dsp_stateless gives -- and the NBFM rows match the reference goldens."""
+    g = golden("chain_analog")
+    fs, n, seed0 = (int(v) for v in g["nbfm_args"])
+    offs = S.nbfm_bank_offsets()
+    iq = wh.unpack_iq16(S.pack_iq16_np(S.nbfm_bank_c64(n, fs, seed=seed0, start=0)))
+    cfgs = [_nbfm_cfg(wh, offs[0]), wh.ChannelConfig(mode="raw", offset_hz=offs[5]), _nbfm_cfg(wh, offs[13]),
+            wh.ChannelConfig(mode="wbfm", offset_hz=0.0), wh.ChannelConfig(mode="p25", offset_hz=offs[7]),
+            _nbfm_cfg(wh, offs[31]),
+            wh.ChannelConfig(mode="nbfm", offset_hz=offs[20], enable_deemphasis=True, enable_fm_lowpass=True)]
+    disp = wh.ChannelDispatcher(fs)
+    res = disp.process(iq, cfgs)
+    assert len(res) == len(cfgs) and len(disp._banks) == 3
+    for k, i in ((0, 0), (13, 2), (31, 5)):
+        assert peak_rel_err(res[i][0], g[f"nbfm0_k{k}_audio"]) <= TOL
+        assert np.abs(np.array([res[i][1]["rssi_db"], res[i][1]["signal_power_db"]]) - g[f"nbfm0_k{k}_met"]).max() <= 2e-4
+    for i, c in enumerate(cfgs):
+        a, m = wh.process_channel_dsp_stateless(iq, fs, c)
+        if a is None:
+            assert res[i][0] is None
+        else:
+            assert np.array_equal(res[i][0], a), i
+        assert res[i][1] == m, i
+    again = disp.process(iq, cfgs)                               # cached banks, same results
+    assert len(disp._banks) == 3 and all(np.array_equal(a[0], b[0]) for a, b in zip(res, again) if a[0] is not None)
+    bad = iq.copy()
+    bad[3] = np.inf
+    assert disp.process(bad, cfgs) == [(None, {})] * len(cfgs)
+    assert disp.process(iq, []) == [] and disp.process(iq[:0], cfgs) == [(None, {})] * len(cfgs)

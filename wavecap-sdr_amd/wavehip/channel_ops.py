@@ -352,8 +352,11 @@ class ChannelBank:
         if self.input_format == 0 and not np.isfinite(x.view(np.float32)).all():  # capture.py:323-325
             logger.warning("ChannelBank: non-finite IQ samples, dropping DSP chunk")
             return [(None, {}) for _ in range(self.K)]
-        audio, met = self.process_device(torch.from_numpy(x).cuda(), 1)
-        audio, met = audio[0].cpu().numpy(), met[0].cpu().numpy()
+        return self.collect(*self.process_device(torch.from_numpy(x).cuda(), 1))
+
+    def collect(self, audio_dev, met_dev) -> list[tuple[np.ndarray | None, dict[str, Any]]]:
+        """Device results of ONE chunk -> the reference's (audio | None, metrics) per channel."""
+        audio, met = audio_dev[0].cpu().numpy(), met_dev[0].cpu().numpy()
         out = []
         for k in range(self.K):
             m: dict[str, Any] = {"rssi_db": float(met[k, 0])}
@@ -453,3 +456,62 @@ def process_channel_dsp_stateless(samples, sample_rate: int, cfg) -> tuple[np.nd
             _bank_cache.pop(next(iter(_bank_cache)))
         bank = _bank_cache[key] = ChannelBank(sample_rate, samples.shape[0], [cfg])
     return bank.process(samples)[0]
+
+
+class ChannelDispatcher:
+    """Batched replacement for the DSP fan-out of Capture._process_channels_parallel (capture.py:2489-2597, SURVEY
+    8(f) N1): instead of one thread-pool task per running channel, the chunk is uploaded ONCE and every group of
+    channels that shares a chain (mode + filter settings + audio rate) runs as one ChannelBank launch sequence;
+    "raw" and the digital-voice modes (metrics only) ride along.  `process(samples, cfgs)` returns
+    [(audio | None, metrics)] in the order of `cfgs`, with the conventions of _process_channel_dsp_stateless;
+    the stateful tail (RDS / POCSAG / P25 decoders, audio metrics) stays with the caller, squelch can be fused
+    (`apply_squelch=True`).  Banks are cached per (chunk length, chain, offsets): a channel set that does not
+    change costs no set-up after the first chunk."""
+
+    def __init__(self, sample_rate: int, apply_squelch: bool = False, max_banks: int = 32):
+        self._torch = _lib.require_gpu()
+        self.sample_rate = int(sample_rate)
+        self.apply_squelch = bool(apply_squelch)
+        self.max_banks = int(max_banks)
+        self._banks: dict[tuple, ChannelBank] = {}
+
+    def process(self, samples, cfgs) -> list[tuple[np.ndarray | None, dict[str, Any]]]:
+        torch = self._torch
+        cfgs = list(cfgs)
+        if not cfgs:
+            return []
+        x = np.ascontiguousarray(samples, dtype=np.complex64)
+        n = x.shape[0]
+        if n == 0:
+            return [(None, {}) for _ in cfgs]
+        if not np.isfinite(x.view(np.float32)).all():          # capture.py:323-325, once for all channels
+            logger.warning("ChannelDispatcher: non-finite IQ samples, dropping DSP chunk")
+            return [(None, {}) for _ in cfgs]
+        results: list[Any] = [None] * len(cfgs)
+        groups: dict[tuple, list[int]] = {}
+        for i, c in enumerate(cfgs):
+            if c.mode == "raw" or c.mode in DIGITAL_MODES:
+                results[i] = _raw_or_digital(x, self.sample_rate, c)
+                continue
+            why = _unsupported(c)
+            if why:
+                raise NotImplementedError(f"wavehip: {why} is not implemented on the device")
+            groups.setdefault(_chain_key(c), []).append(i)
+        if groups:
+            d_in = torch.from_numpy(x).cuda()
+            launched = []
+            for key, idx in groups.items():
+                offs = tuple(int(round(float(cfgs[i].offset_hz))) for i in idx)
+                sq = tuple(getattr(cfgs[i], "squelch_db", None) for i in idx) if self.apply_squelch else ()
+                bkey = (n, key, offs, sq)
+                bank = self._banks.get(bkey)
+                if bank is None:
+                    if len(self._banks) >= self.max_banks:
+                        self._banks.pop(next(iter(self._banks)))
+                    bank = self._banks[bkey] = ChannelBank(self.sample_rate, n, [cfgs[i] for i in idx],
+                                                           apply_squelch=self.apply_squelch)
+                launched.append((bank, idx, bank.process_device(d_in, 1)))    # all groups queued before any read-back
+            for bank, idx, (audio, met) in launched:
+                for i, r in zip(idx, bank.collect(audio, met)):
+                    results[i] = r
+        return results
