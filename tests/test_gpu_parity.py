@@ -740,3 +740,31 @@ def test_n1_channel_dispatcher_mixed_modes(wh, golden):
     bad[3] = np.inf
     assert disp.process(bad, cfgs) == [(None, {})] * len(cfgs)
     assert disp.process(iq, []) == [] and disp.process(iq[:0], cfgs) == [(None, {})] * len(cfgs)
+
+
+def test_chain_scan_form_equals_sequential(wh, monkeypatch):
+    """The exact scan form of the rows (zero-state pass, start states s' = M s + e, output pass; AGC envelopes
+    likewise) against the strictly sequential kernel (WH_IIR_SEQ=1) at capture rate, for chains whose transition
+    powers are well conditioned: AM envelope + AGC at capture rate, AM low-pass (+ AGC) at 96 kS/s.  Chains containing one of the
+    reference's order-5 ba-form Butterworths are refused by the host check (|M| ~ 4e6 for the 100 Hz high-pass at
+    48 kS/s; at 2.4 MS/s even the 5 kHz low-pass is clustered at z = 1) and stay sequential."""
+    from wavehip.channel_ops import build_chain, iir_scan_safe
+    C = wh.ChannelConfig
+    cases = [
+        (2_400_000, 120_000, C(mode="am", offset_hz=100e3, enable_agc=True, enable_am_highpass=False, enable_am_lowpass=False)),
+        (96_000, 9_600, C(mode="am", offset_hz=9600.0, enable_agc=True, enable_am_highpass=False)),      # low-pass + AGC
+        (96_000, 9_600, C(mode="am", offset_hz=9600.0, enable_agc=False, enable_am_highpass=False)),     # low-pass only
+    ]
+    assert not iir_scan_safe(build_chain(C(mode="am", enable_agc=True), 48000)[2], 75)
+    assert not iir_scan_safe(build_chain(C(mode="am", enable_agc=True, enable_am_highpass=False), 2_400_000)[2], 1875)
+    for k, (fs, n, cfg) in enumerate(cases):
+        assert iir_scan_safe(build_chain(cfg, fs)[2], (n + 63) // 64)
+        iq = S.am_tone_c64(n, fs, seed=590 + k, carrier_hz=float(cfg.offset_hz), depth=0.7)
+        import torch
+        d = torch.from_numpy(iq).cuda()
+        par, mp = (t.cpu().numpy() for t in wh.ChannelBank(fs, n, [cfg]).process_device(d, 1))
+        monkeypatch.setenv("WH_IIR_SEQ", "1")
+        seq, ms = (t.cpu().numpy() for t in wh.ChannelBank(fs, n, [cfg]).process_device(d, 1))
+        monkeypatch.delenv("WH_IIR_SEQ")
+        assert np.isfinite(par).all() and peak_rel_err(par[0, 0], seq[0, 0]) <= 5e-6, (k, peak_rel_err(par[0, 0], seq[0, 0]))
+        assert abs(mp[0, 0, 1] - ms[0, 0, 1]) <= 1e-4

@@ -35,4 +35,6 @@ run("wbfm default", fs, n, [C(mode="wbfm", offset_hz=k * 200e3 - 800e3) for k in
 run("am agc (250 kS/s)", 250_000, 12_500, [C(mode="am", offset_hz=k * 1e4, enable_agc=True) for k in range(16)], 100)
 run("ssb agc (250 kS/s)", 250_000, 12_500, [C(mode="ssb", offset_hz=k * 1e4, enable_agc=True) for k in range(16)], 100)
 run("sam (250 kS/s)", 250_000, 12_500, [C(mode="sam", offset_hz=k * 1e4, enable_agc=True) for k in range(16)], 100)
+run("am agc only (2.4 MS/s)", fs, n, [C(mode="am", offset_hz=k * 1e5, enable_agc=True, enable_am_highpass=False, enable_am_lowpass=False) for k in range(8)], 25)
+run("am agc only (2.4 MS/s)", fs, n, [C(mode="am", offset_hz=1e5, enable_agc=True, enable_am_highpass=False, enable_am_lowpass=False)], 1)
 run("nbfm + noise reduction", fs, n, [C(mode="nbfm", offset_hz=k * 25e3, enable_deemphasis=False, enable_noise_reduction=True) for k in range(32)], 20)

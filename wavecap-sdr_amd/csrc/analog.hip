@@ -490,6 +490,8 @@ constexpr int ROWS_CH = 64;
 
 template <int NC, bool F64>
 __device__ __forceinline__ void iir_run(float (*tile)[65], int cnt, int lane, double (&z)[MAX_ORD - 1], const StageDev &S) {
+    // S lives in LDS: the coefficients arrive in VGPRs (read from the scalar kernarg copy the compiler keeps them in
+    // SGPRs, runs out of those and round-trips them through v_readlane inside the sample loop)
     double b[NC], a[NC];
 #pragma unroll
     for (int k = 0; k < NC; ++k) { b[k] = S.b[k]; a[k] = S.a[k]; }
@@ -517,7 +519,7 @@ __device__ __forceinline__ void iir_run(float (*tile)[65], int cnt, int lane, do
 
 template <bool F64>
 __device__ __forceinline__ void iir_stage(float (*tile)[65], int cnt, int lane, double (&z)[MAX_ORD - 1], const StageDev &S) {
-    switch (S.n) {   // wave-uniform, once per (tile, stage)
+    switch (__builtin_amdgcn_readfirstlane(S.n)) {   // wave-uniform, once per (tile, stage)
         case 1: iir_run<1, F64>(tile, cnt, lane, z, S); break;
         case 2: iir_run<2, F64>(tile, cnt, lane, z, S); break;
         case 3: iir_run<3, F64>(tile, cnt, lane, z, S); break;
@@ -547,7 +549,11 @@ template <int NS>
 __global__ __launch_bounds__(64) void chan_rows_kernel(float *rows, double *acc, int n_rows, int N, StageArr sa,
                                                       AgcDev agc, int seg, int warm) {
     __shared__ float tile[ROWS_CH][65];   // [sample][row], padded: column walks and row walks are both conflict-free
+    __shared__ StageDev st_s[NS > 0 ? NS : 1];
     const int lane = threadIdx.x;
+    for (int i = lane; i < NS * (int)(sizeof(StageDev) / 4); i += 64)
+        reinterpret_cast<int *>(st_s)[i] = reinterpret_cast<const int *>(sa.st)[i];
+    __syncthreads();
     const int r0 = seg ? blockIdx.x : blockIdx.x * 64;
     int nr = seg ? (N + seg - 1) / seg : n_rows - r0;   // live lanes (virtual rows)
     if (nr > 64) nr = 64;
@@ -593,8 +599,8 @@ __global__ __launch_bounds__(64) void chan_rows_kernel(float *rows, double *acc,
             if (cnt > 0) {
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
-                    if (sa.st[s].is_f64) iir_stage<true>(tile, cnt, lane, z[s], sa.st[s]);
-                    else iir_stage<false>(tile, cnt, lane, z[s], sa.st[s]);
+                    if (sa.st[s].is_f64) iir_stage<true>(tile, cnt, lane, z[s], st_s[s]);
+                    else iir_stage<false>(tile, cnt, lane, z[s], st_s[s]);
                 }
                 if (agc.on) {
                     for (int j = 0; j < cnt; ++j) {
@@ -634,6 +640,222 @@ __global__ __launch_bounds__(64) void chan_rows_kernel(float *rows, double *acc,
     } else if (lane < nr) {
         acc[(size_t)(r0 + lane) * 2 + 1] = ss;
     }
+}
+
+// ---- exact time-parallel form of the rows (linear-recurrence scan) ---------------------------------------------
+// For chains the warm-up trick cannot serve (poles too close to the unit circle for the chunk, or the AGC, whose
+// release constant spans the chunk): a wave owns one row cut into 64 segments and every stage runs in three steps --
+//   1. each lane runs the stage over its segment from ZERO state and keeps only the end state e_p;
+//   2. the true start states follow from s_{p+1} = M s_p + e_p, M = (state transition)^segment, 63 small mat-vecs;
+//   3. each lane re-runs the stage over its segment from s_p and writes the outputs --
+// the same DF2T operations as the sequential kernel in step 3; only the start states carry the rounding of the
+// scan instead of that of the sequential walk.  M is produced at bank creation by the recurrence itself on the unit
+// state vectors (iir_pow_kernel).  The AGC's two one-pole envelopes (float32, linear in |x|) take the same treatment:
+// attack envelope scan, release envelope scan, then the gain / tanh pass.
+struct ScanPow {
+    double m[MAX_STAGES][MAX_ORD - 1][MAX_ORD - 1];   // per stage: M[i][j]
+    double att, rel;                                  // (-a1)^segment of the two AGC one-poles
+};
+
+__global__ void iir_pow_kernel(StageArr sa, int n_stages, AgcDev agc, int seg, ScanPow *out) {
+    // thread (s, j): column j of stage s: state after `seg` zero-input steps from the unit vector e_j
+    const int s = blockIdx.x, j = threadIdx.x;
+    if (s < n_stages) {
+        const StageDev &S = sa.st[s];
+        const int m = S.n - 1;
+        if (j < m) {
+            double z[MAX_ORD - 1];
+            for (int k = 0; k < MAX_ORD - 1; ++k) z[k] = k == j ? 1.0 : 0.0;
+            for (int t = 0; t < seg; ++t) {
+                if (S.is_f64) {
+                    const double y = z[0];
+                    for (int k = 0; k < m - 1; ++k) z[k] = __dsub_rn(z[k + 1], __dmul_rn(y, S.a[k + 1]));
+                    z[m - 1] = -__dmul_rn(y, S.a[m]);
+                } else {
+                    const float y = (float)z[0];
+                    for (int k = 0; k < m - 1; ++k) z[k] = (double)__fsub_rn((float)z[k + 1], __fmul_rn(y, (float)S.a[k + 1]));
+                    z[m - 1] = (double)(-__fmul_rn(y, (float)S.a[m]));
+                }
+            }
+            for (int i = 0; i < MAX_ORD - 1; ++i) out->m[s][i][j] = i < m ? z[i] : 0.0;
+        }
+    } else if (j == 0) {
+        float za = 1.0f, zr = 1.0f;   // z' = -a1 * y, y = z (zero input)
+        for (int t = 0; t < seg; ++t) {
+            za = -__fmul_rn(za, agc.att_a1);
+            zr = -__fmul_rn(zr, agc.rel_a1);
+        }
+        out->att = (double)za;
+        out->rel = (double)zr;
+    }
+}
+
+template <int NC>
+__device__ __forceinline__ void scan_states(double (&z)[MAX_ORD - 1], const double (*M)[MAX_ORD - 1], int lane, bool f64) {
+    constexpr int m = NC - 1;
+    double cur[m > 0 ? m : 1], mine[m > 0 ? m : 1];
+#pragma unroll
+    for (int k = 0; k < m; ++k) { cur[k] = 0.0; mine[k] = 0.0; }
+    for (int p = 0; p < 63; ++p) {
+        double nxt[m > 0 ? m : 1];
+#pragma unroll
+        for (int i = 0; i < m; ++i) {
+            double acc = __shfl(z[i], p);
+#pragma unroll
+            for (int j = 0; j < m; ++j) acc = fma(M[i][j], cur[j], acc);
+            nxt[i] = f64 ? acc : (double)(float)acc;
+        }
+#pragma unroll
+        for (int i = 0; i < m; ++i) {
+            cur[i] = nxt[i];
+            if (lane == p + 1) mine[i] = nxt[i];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < m; ++k) z[k] = mine[k];
+}
+
+__device__ __forceinline__ void scan_stage_states(double (&z)[MAX_ORD - 1], const double (*M)[MAX_ORD - 1], int n, int lane,
+                                                  bool f64) {
+    switch (n) {
+        case 2: scan_states<2>(z, M, lane, f64); break;
+        case 3: scan_states<3>(z, M, lane, f64); break;
+        case 4: scan_states<4>(z, M, lane, f64); break;
+        case 5: scan_states<5>(z, M, lane, f64); break;
+        case 6: scan_states<6>(z, M, lane, f64); break;
+        case 7: scan_states<7>(z, M, lane, f64); break;
+        case 8: scan_states<8>(z, M, lane, f64); break;
+        case 9: scan_states<9>(z, M, lane, f64); break;
+        case 10: scan_states<10>(z, M, lane, f64); break;
+        case 11: scan_states<11>(z, M, lane, f64); break;
+        default: break;   // n == 1: no state
+    }
+}
+
+// scalar affine scan for a one-pole: start_{p+1} = pw * start_p + e_p (float64, rounded to float32 each step)
+__device__ __forceinline__ float scan_scalar(float e, double pw, int lane) {
+    double cur = 0.0;
+    float mine = 0.0f;
+    for (int p = 0; p < 63; ++p) {
+        cur = (double)(float)fma(pw, cur, (double)__shfl(e, p));
+        if (lane == p + 1) mine = (float)cur;
+    }
+    return mine;
+}
+
+__global__ __launch_bounds__(64) void chan_rows_scan_kernel(float *rows, double *acc, int N, StageArr sa, int n_stages,
+                                                           AgcDev agc, int seg, const ScanPow *pw) {
+    __shared__ float tile[ROWS_CH][65];
+    __shared__ StageDev st_s[MAX_STAGES];
+    __shared__ double M_s[MAX_ORD - 1][MAX_ORD - 1];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < n_stages * (int)(sizeof(StageDev) / 4); i += 64)
+        reinterpret_cast<int *>(st_s)[i] = reinterpret_cast<const int *>(sa.st)[i];
+    __syncthreads();
+    float *row = rows + (size_t)blockIdx.x * N;
+    int nr = (N + seg - 1) / seg;
+    if (nr > 64) nr = 64;
+    auto vn = [&](int l) -> int {
+        const int left = N - l * seg;
+        return left < seg ? (left > 0 ? left : 0) : seg;
+    };
+    const int my_n = lane < nr ? vn(lane) : 0;
+    // stream the segment through the tile; body(cnt) works on tile[0..cnt)[lane]
+    auto stream = [&](bool write, auto body) {
+        for (int i0 = 0; i0 < seg; i0 += ROWS_CH) {
+            for (int l0 = 0; l0 < nr; l0 += 16) {
+                float v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int l = l0 + u;
+                    v[u] = (l < nr && lane < vn(l) - i0) ? row[(size_t)l * seg + i0 + lane] : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (l0 + u < nr) tile[lane][l0 + u] = v[u];
+            }
+            __syncthreads();
+            int cnt = my_n - i0;
+            if (cnt > ROWS_CH) cnt = ROWS_CH;
+            if (cnt > 0) body(cnt);
+            __syncthreads();
+            if (write)
+                for (int l = 0; l < nr; ++l)
+                    if (lane < vn(l) - i0) row[(size_t)l * seg + i0 + lane] = tile[lane][l];
+            __syncthreads();
+        }
+    };
+    double ss = 0.0;
+    for (int s = 0; s < n_stages; ++s) {
+        const bool f64 = st_s[s].is_f64 != 0;
+        const int n = __builtin_amdgcn_readfirstlane(st_s[s].n);
+        for (int i = lane; i < (MAX_ORD - 1) * (MAX_ORD - 1); i += 64) (&M_s[0][0])[i] = (&pw->m[s][0][0])[i];
+        double z[MAX_ORD - 1];
+#pragma unroll
+        for (int k = 0; k < MAX_ORD - 1; ++k) z[k] = 0.0;
+        auto run = [&](int cnt) {
+            if (f64) iir_stage<true>(tile, cnt, lane, z, st_s[s]);
+            else iir_stage<false>(tile, cnt, lane, z, st_s[s]);
+        };
+        stream(false, run);                       // 1. zero-state end states
+        __syncthreads();
+        scan_stage_states(z, M_s, n, lane, f64);  // 2. true start states
+        const bool last = (s == n_stages - 1) && !agc.on;
+        stream(true, [&](int cnt) {               // 3. the outputs
+            run(cnt);
+            if (last)
+                for (int j = 0; j < cnt; ++j) {
+                    float x = tile[j][lane];
+                    ss += (double)x * (double)x;
+                }
+        });
+        __syncthreads();
+    }
+    if (agc.on) {
+        const float NORM = (float)(1.0 / 0.90514825364486640);
+        float za = 0.f, zr = 0.f;
+        // attack envelope: zero-state end value, scan
+        stream(false, [&](int cnt) {
+            for (int j = 0; j < cnt; ++j) {
+                float ya = __fadd_rn(za, __fmul_rn(agc.att_b0, fabsf(tile[j][lane])));
+                za = __fsub_rn(0.0f, __fmul_rn(ya, agc.att_a1));
+            }
+        });
+        const float za0 = scan_scalar(za, pw->att, lane);
+        // release envelope fed by the true attack envelope: zero-state end value, scan
+        za = za0;
+        stream(false, [&](int cnt) {
+            for (int j = 0; j < cnt; ++j) {
+                float ax = fabsf(tile[j][lane]);
+                float ya = __fadd_rn(za, __fmul_rn(agc.att_b0, ax));
+                za = __fsub_rn(__fmul_rn(ax, 0.0f), __fmul_rn(ya, agc.att_a1));
+                float yr = __fadd_rn(zr, __fmul_rn(agc.rel_b0, ya));
+                zr = __fsub_rn(__fmul_rn(ya, 0.0f), __fmul_rn(yr, agc.rel_a1));
+            }
+        });
+        const float zr0 = scan_scalar(zr, pw->rel, lane);
+        za = za0;
+        zr = zr0;
+        stream(true, [&](int cnt) {
+            for (int j = 0; j < cnt; ++j) {
+                float x = tile[j][lane];
+                float ax = fabsf(x);
+                float ya = __fadd_rn(za, __fmul_rn(agc.att_b0, ax));
+                za = __fsub_rn(__fmul_rn(ax, 0.0f), __fmul_rn(ya, agc.att_a1));
+                float yr = __fadd_rn(zr, __fmul_rn(agc.rel_b0, ya));
+                zr = __fsub_rn(__fmul_rn(ya, 0.0f), __fmul_rn(yr, agc.rel_a1));
+                float env = fmaxf(ya, yr);
+                float g = __fdiv_rn(agc.target, fmaxf(env, (float)1e-6));
+                g = fminf(g, agc.max_gain);
+                float y = __fmul_rn(x, g);
+                x = tanhf(y * 1.5f) * NORM;
+                tile[j][lane] = x;
+                ss += (double)x * (double)x;
+            }
+        });
+    }
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    if (lane == 0) acc[(size_t)blockIdx.x * 2 + 1] = ss;
 }
 
 // finalize.  post 0 (FM): scale by 0.18/rms (dsp/fm.py:42-62) + soft clip x0.95 (fm.py:26-39);
@@ -965,6 +1187,8 @@ struct wh_chanbank {
     float *d_squelch = nullptr;
     double *d_taps = nullptr;
     StageArr stages{};
+    ScanPow *d_pow = nullptr;   // scan form: per-stage state-transition powers for the bank's segment length
+    int scan_seg = 0;
     double *d_acc = nullptr;
     float *d_fm = nullptr;
     size_t cap_chunks = 0;
@@ -1055,6 +1279,23 @@ extern "C" int wh_chanbank_create(wh_chanbank **out, const wh_chanbank_cfg *c) {
         }
         for (int i = 0; i < c->n_stages; ++i) b->stages.st[i] = sd[i];
     }
+    // exact scan form of the rows for long chunks that the warm-up form cannot take (see chan_rows_scan_kernel)
+    if (c->iir_scan && (c->n_stages > 0 || c->agc) && c->chunk_len >= 4096) {
+        const int sg = (c->chunk_len + 63) / 64;
+        const bool warm_ok = !c->agc && c->iir_warmup > 0 && c->n_stages > 0 && sg + c->iir_warmup <= c->chunk_len / 2;
+        if (!warm_ok) {
+            b->scan_seg = sg;
+            AgcDev g;
+            g.on = c->agc; g.target = c->agc_target; g.max_gain = c->agc_max_gain;
+            g.att_b0 = c->agc_att_b0; g.att_a1 = c->agc_att_a1; g.rel_b0 = c->agc_rel_b0; g.rel_a1 = c->agc_rel_a1;
+            WH_HIP(hipMalloc(&b->d_pow, sizeof(ScanPow)));
+            WH_HIP(hipMemset(b->d_pow, 0, sizeof(ScanPow)));
+            hipLaunchKernelGGL(iir_pow_kernel, dim3(c->n_stages + 1), dim3(MAX_ORD - 1), 0, nullptr, b->stages, c->n_stages, g,
+                               sg, b->d_pow);
+            WH_LAUNCH_CHECK();
+            WH_HIP(hipDeviceSynchronize());
+        }
+    }
     // fused path: plain FM (no IIR stage, no AGC), pure decimation, everything fits in LDS
     b->fused = false;
     if (c->demod == 0 && c->n_stages == 0 && !c->agc && c->post == 0 && !b->nr && resample && c->up == 1 &&
@@ -1077,6 +1318,7 @@ extern "C" void wh_chanbank_destroy(wh_chanbank *b) {
     if (!b) return;
     (void)hipFree(b->d_nco);
     (void)hipFree(b->d_squelch);
+    (void)hipFree(b->d_pow);
     (void)hipFree(b->d_taps);
     (void)hipFree(b->d_acc);
     (void)hipFree(b->d_fm);
@@ -1173,7 +1415,13 @@ extern "C" int wh_chanbank_run(wh_chanbank *b, const void *d_in, size_t n_chunks
                 const int sg = (c.chunk_len + 63) / 64;
                 if (sg + c.iir_warmup <= c.chunk_len / 2) seg = sg;
             }
-            if (getenv("WH_IIR_SEQ")) seg = 0;   // diagnostics: force the sequential form
+            const bool force_seq = getenv("WH_IIR_SEQ") != nullptr;   // diagnostics: force the sequential form
+            if (force_seq) seg = 0;
+            if (b->scan_seg && !force_seq) {
+                hipLaunchKernelGGL(chan_rows_scan_kernel, dim3((unsigned)rows), dim3(64), 0, st, a.fm_out, b->d_acc, c.chunk_len,
+                                   b->stages, c.n_stages, g, b->scan_seg, b->d_pow);
+                WH_LAUNCH_CHECK();
+            } else {
             const dim3 rg(seg ? (unsigned)rows : (unsigned)((rows + 63) / 64));
 #define WH_ROWS(NS_) hipLaunchKernelGGL(chan_rows_kernel<NS_>, rg, dim3(64), 0, st, a.fm_out, b->d_acc, (int)rows, c.chunk_len, b->stages, g, seg, c.iir_warmup)
             switch (c.n_stages) {
@@ -1189,6 +1437,7 @@ extern "C" int wh_chanbank_run(wh_chanbank *b, const void *d_in, size_t n_chunks
             }
 #undef WH_ROWS
             WH_LAUNCH_CHECK();
+            }
         }
         if (b->nr) {
             const int F = b->nr_frames;

@@ -65,6 +65,7 @@ class ChanBankCfg(C.Structure):
         ("nr_reduction_linear", c_float),
         ("h_nr_window", C.POINTER(c_float)),
         ("iir_warmup", c_int),
+        ("iir_scan", c_int),
         ("h_squelch_db", C.POINTER(c_float)),
     ]
 

@@ -212,6 +212,25 @@ def iir_warmup_samples(stages, tol: float = 1e-14) -> int:
     return int(n) if n < (1 << 22) else 0
 
 
+def iir_scan_safe(stages, segment: int, limit: float = 64.0) -> bool:
+    """True when every stage's DF2T transition matrix raised to `segment` has entries <= `limit`: then the start
+    states of the scan form (s' = M s + e) carry no cancellation.  The reference's order-5 ba-form high-/band-passes
+    fail this by many orders of magnitude (entries ~1e6 at 48 kS/s), low-passes, notches and one-poles pass."""
+    for st in stages:
+        m = st.n - 1
+        if m < 1:
+            continue
+        a = np.array([st.a[k] for k in range(st.n)], dtype=np.float64) / st.a[0]
+        A = np.zeros((m, m))
+        A[:, 0] = -a[1:]
+        A[np.arange(m - 1), np.arange(1, m)] += 1.0
+        with np.errstate(over="ignore", invalid="ignore"):
+            M = np.linalg.matrix_power(A, int(segment))
+        if not np.isfinite(M).all() or np.abs(M).max() > limit:
+            return False
+    return True
+
+
 def sam_pll_coefficients(sample_rate: int, loop_bandwidth: float, damping: float = 0.707):
     """dsp/sam.py:55-66 (sample_rate as float, Python-float arithmetic in the reference's order)."""
     fs = float(sample_rate)
@@ -270,6 +289,7 @@ class ChannelBank:
         keep = [offs]
         cfg.n_stages = len(stages)
         cfg.iir_warmup = iir_warmup_samples(stages) if (stages and agc is None and demod < 3) else 0
+        cfg.iir_scan = 1 if iir_scan_safe(stages, (self.chunk_len + 63) // 64) else 0
         if stages:
             arr = (_lib.IirStage * len(stages))(*stages)
             cfg.h_stages = arr
