@@ -768,3 +768,24 @@ def test_chain_scan_form_equals_sequential(wh, monkeypatch):
         monkeypatch.delenv("WH_IIR_SEQ")
         assert np.isfinite(par).all() and peak_rel_err(par[0, 0], seq[0, 0]) <= 5e-6, (k, peak_rel_err(par[0, 0], seq[0, 0]))
         assert abs(mp[0, 0, 1] - ms[0, 0, 1]) <= 1e-4
+
+
+def test_chain_nbfm_other_rates_vs_oracle(wh, O):
+    """The fused FM kernel's other shapes against the numpy oracle: odd decimation (240 kS/s -> 48 k: down 5, generic
+    FIR branch), a small even one (192 kS/s: down 4, paired-tap branch with a short window), 1.2 MS/s (down 25, odd)
+    and an interpolating pair (250 kS/s -> 48 k: up 24 / down 125, unfused resampler); int16 and complex64 inputs,
+    several channels per bank, chunk lengths that are not multiples of the tile."""
+    for fs, n in ((240_000, 12_000), (192_000, 9_613), (1_200_000, 60_000), (250_000, 12_500)):
+        offs = [-fs / 5.0, 0.0, fs / 7.0]
+        iq = sum(S.fm_tone_c64(n, fs, seed=600 + k, audio_hz=500.0 + 300 * k, deviation=3000.0, carrier_hz=o, noise_amp=0.01, amp=0.3)
+                 for k, o in enumerate(offs)).astype(np.complex64)
+        i16 = S.pack_iq16_np(iq)
+        z = wh.unpack_iq16(i16)
+        cfgs = [_nbfm_cfg(wh, o) for o in offs]
+        for fmt, x in (("cf32", z), ("int16", i16)):
+            res = wh.ChannelBank(fs, n, cfgs, input_format=fmt).process(x)
+            for k, o in enumerate(offs):
+                ref, met = O.process_channel_nbfm(z, fs, o)
+                assert res[k][0].shape == ref.shape, (fs, k)
+                assert peak_rel_err(res[k][0], ref) <= TOL, (fs, fmt, k, peak_rel_err(res[k][0], ref))
+                assert abs(res[k][1]["rssi_db"] - met["rssi_db"]) <= 2e-4
