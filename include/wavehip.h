@@ -118,7 +118,7 @@ typedef struct wh_chanbank_cfg {
                                ((N-1024)/512)*512 + 1024 samples and n_out must be computed from that length */
     float nr_reduction_linear;      /* float32(10^(noise_reduction_db/20)) */
     const float *h_nr_window;       /* float32[1024] scipy.signal.windows.hann(1024, sym=False) */
-    int iir_warmup;                 /* > 0: every IIR stage's impulse response has decayed below 1e-14 after this many
+    int iir_warmup;                 /* > 0: every IIR stage's impulse response has decayed below 1e-10 after this many
                                        samples (derived by the host from the pole radii); lets chains without AGC run
                                        time-parallel (64 segments per row, each warmed up over iir_warmup samples);
                                        0 = strictly sequential recurrences */

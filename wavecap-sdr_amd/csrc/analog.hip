@@ -540,9 +540,9 @@ __device__ __forceinline__ void iir_stage(float (*tile)[65], int cnt, int lane, 
 // tile is written back coalesced.
 //   seg == 0: a wave owns 64 (chunk, channel) rows, one lane each, zero initial state (the stateless operator).
 //   seg  > 0: TIME-PARALLEL mode for chains whose impulse responses have died out after `warm` samples (the host
-//             derives `warm` from the pole radii, target 1e-14): a wave owns ONE row cut into 64 segments of `seg`
+//             derives `warm` from the pole radii, target 1e-10): a wave owns ONE row cut into 64 segments of `seg`
 //             samples; pass A runs every lane over the `warm` samples before its segment (from zero state, nothing
-//             written: the true state differs by < 1e-14 relative), pass B runs it over its segment in place.  64x less
+//             written: the true state differs by < 1e-10 relative), pass B runs it over its segment in place.  64x less
 //             sequential depth for (seg + warm) / seg times the arithmetic.  Not available with the AGC (its release
 //             time constant spans the chunk).
 template <int NS>

@@ -189,8 +189,9 @@ def build_chain(cfg, sample_rate: int):
     return demod, float(bfo), stages, agc, post
 
 
-def iir_warmup_samples(stages, tol: float = 1e-14) -> int:
-    """Samples after which the impulse response of every stage of the cascade is below `tol` (relative): from the
+def iir_warmup_samples(stages, tol: float = 1e-10) -> int:
+    """Samples after which the impulse response of every stage of the cascade is below `tol` (relative; the outputs
+    are float32, 6e-8, and the parity bar is 1e-5): from the
     largest pole radius rho, n = log(tol) / log(rho), padded for the polynomial factor of clustered poles.  0 when a
     pole sits on / outside the unit circle or the answer is useless (> 2^22)."""
     rho, order = 0.0, 0
