@@ -102,3 +102,27 @@ def test_config4_c4fm_64ch_10s_bit_exact():
             assert np.array_equal(dc[c, :cc[c]], rd) and np.array_equal(sc[c, :cc[c]], rs), (c, s)
     assert int(total.min()) >= 47990 and int(total.max()) <= 48010
     assert all(r.state()["sync_count"] > 100 for r in refs.values())
+
+
+def test_config1_wbfm_10s_single_channel():
+    """BASELINE configs[0]: one default WBFM channel, 10 s of a 2.4 MS/s complex64 stream (200 chunks) in one launch:
+    every chunk equals that chunk run alone (stateless operator; the time-parallel IIR form is per row), and the
+    numpy oracle agrees on two chunks."""
+    import torch
+    import wavehip
+    from oracle import ref_np as O
+
+    fs, n, chunks = 2_400_000, 120_000, 200
+    cfg = wavehip.ChannelConfig(mode="wbfm", offset_hz=0.0)
+    bank = wavehip.ChannelBank(fs, n, [cfg])
+    parts = [S.fm_tone_c64(n, fs, seed=950 + c, audio_hz=400.0 + 300 * c, noise_amp=0.05) for c in range(4)]
+    x = np.concatenate([parts[c % 4] for c in range(chunks)])
+    a, m = bank.process_device(torch.from_numpy(x).cuda(), chunks)
+    assert a.shape == (chunks, 1, 2400) and bool(torch.isfinite(a).all())
+    for c in (0, 101, 199):
+        a1, m1 = bank.process_device(torch.from_numpy(parts[c % 4]).cuda(), 1)
+        assert torch.equal(a1[0], a[c]) and torch.allclose(m1[0], m[c], atol=1e-5)
+    for c in (2, 199):
+        ref, met = O.process_channel_wbfm(parts[c % 4], fs, 0.0)
+        assert peak_rel_err(a[c, 0].cpu().numpy(), ref) <= 1e-5
+        assert abs(float(m[c, 0, 0]) - met["rssi_db"]) <= 2e-4
