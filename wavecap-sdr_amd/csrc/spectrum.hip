@@ -24,21 +24,41 @@ __global__ __launch_bounds__(256) void spectrum_kernel(const float2 *iq, size_t 
     const int shift = N - N / 2;  // fftshift: shifted[i] = X[(i + ceil(N/2)) mod N]
     if (log2N > 0) {
         float2 *src = sm, *dst = sm + N;
-        const int half = N >> 1;
         int n = N, s = 1;
-        for (int st = 0; st < log2N; ++st) {
-            const int m = n >> 1;
-            for (int i = threadIdx.x; i < half; i += 256) {
-                int pp = i / s, q = i - pp * s;
-                float2 c0 = src[q + s * pp];
-                float2 c1 = src[q + s * (pp + m)];
-                float2 w = tw[(size_t)pp * s];
-                dst[q + s * 2 * pp] = cadd(c0, c1);
-                dst[q + s * (2 * pp + 1)] = cmul(csub(c0, c1), w);
+        // autosort Stockham: radix-4 passes (half the LDS round trips and barriers of radix-2), one radix-2 pass at the
+        // end when log2(N) is odd
+        for (int st = 0; st + 1 < log2N; st += 2) {
+            const int m = n >> 2;
+            for (int i = threadIdx.x; i < (N >> 2); i += 256) {
+                const int pp = i / s, q = i - pp * s;
+                const float2 a = src[q + s * pp];
+                const float2 b = src[q + s * (pp + m)];
+                const float2 c = src[q + s * (pp + 2 * m)];
+                const float2 d = src[q + s * (pp + 3 * m)];
+                const float2 w1 = tw[(size_t)pp * s];
+                const float2 w2 = tw[(size_t)2 * pp * s];
+                const float2 w3 = tw[(size_t)3 * pp * s];
+                const float2 apc = cadd(a, c), amc = csub(a, c), bpd = cadd(b, d), bmd = csub(b, d);
+                const float2 jbmd = make_float2(-bmd.y, bmd.x);               // j (b - d)
+                dst[q + s * (4 * pp)] = cadd(apc, bpd);
+                dst[q + s * (4 * pp + 1)] = cmul(csub(amc, jbmd), w1);          // a - j b - c + j d
+                dst[q + s * (4 * pp + 2)] = cmul(csub(apc, bpd), w2);
+                dst[q + s * (4 * pp + 3)] = cmul(cadd(amc, jbmd), w3);          // a + j b - c - j d
             }
             __syncthreads();
             float2 *tmp = src; src = dst; dst = tmp;
-            n = m; s <<= 1;
+            n = m; s <<= 2;
+        }
+        if (log2N & 1) {   // n == 2 here
+            const int half = N >> 1;
+            for (int i = threadIdx.x; i < half; i += 256) {
+                float2 c0 = src[i];
+                float2 c1 = src[i + half];
+                dst[i] = cadd(c0, c1);
+                dst[i + half] = csub(c0, c1);
+            }
+            __syncthreads();
+            float2 *tmp = src; src = dst; dst = tmp;
         }
         for (int i = threadIdx.x; i < N; i += 256) {
             int k = i + shift;
