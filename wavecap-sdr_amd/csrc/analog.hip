@@ -1078,25 +1078,32 @@ extern "C" int wh_resampler_run(wh_resampler *r, const float *d_x, size_t n_in, 
 // returns output[:len(x)] of a buffer that is only padded_length long).
 constexpr int NR_FFT = 1024, NR_HOP = 512, NR_BINS = 513;
 
-// in-place-free LDS Stockham radix-2, 1024 points, 256 threads; sign = -1 forward, +1 inverse (unscaled).
-// Returns the buffer holding the result.
+// LDS autosort Stockham FFT, 1024 points = five radix-4 passes, 256 threads (one butterfly each per pass);
+// sign = -1 forward, +1 inverse (unscaled).  Returns the buffer holding the result.
 __device__ __forceinline__ float2 *nr_fft1024(float2 *src, float2 *dst, const float2 *tw, float sign) {
     int n = NR_FFT, s = 1;
-    for (int st = 0; st < 10; ++st) {
-        const int m = n >> 1;
-        for (int i = threadIdx.x; i < NR_FFT / 2; i += 256) {
-            int pp = i / s, q = i - pp * s;
-            float2 c0 = src[q + s * pp];
-            float2 c1 = src[q + s * (pp + m)];
-            float2 w = tw[(size_t)pp * s];
-            w.y *= -sign;   // table holds exp(-2 pi i k / N)
-            dst[q + s * 2 * pp] = make_float2(c0.x + c1.x, c0.y + c1.y);
-            float2 d = make_float2(c0.x - c1.x, c0.y - c1.y);
-            dst[q + s * (2 * pp + 1)] = make_float2(d.x * w.x - d.y * w.y, d.x * w.y + d.y * w.x);
-        }
+    for (int st = 0; st < 5; ++st) {
+        const int m = n >> 2;
+        const int i = threadIdx.x;
+        const int pp = i / s, q = i - pp * s;
+        const float2 a = src[q + s * pp];
+        const float2 b = src[q + s * (pp + m)];
+        const float2 c = src[q + s * (pp + 2 * m)];
+        const float2 d = src[q + s * (pp + 3 * m)];
+        float2 w1 = tw[(size_t)pp * s], w2 = tw[(size_t)2 * pp * s], w3 = tw[(size_t)3 * pp * s];
+        w1.y *= -sign; w2.y *= -sign; w3.y *= -sign;   // table holds exp(-2 pi i k / N)
+        const float2 apc = make_float2(a.x + c.x, a.y + c.y), amc = make_float2(a.x - c.x, a.y - c.y);
+        const float2 bpd = make_float2(b.x + d.x, b.y + d.y), bmd = make_float2(b.x - d.x, b.y - d.y);
+        const float2 r = make_float2(-sign * bmd.y, sign * bmd.x);   // forward (sign -1): -j (b - d); inverse: +j (b - d)
+        const float2 y1 = make_float2(amc.x + r.x, amc.y + r.y), y3 = make_float2(amc.x - r.x, amc.y - r.y);
+        const float2 y2 = make_float2(apc.x - bpd.x, apc.y - bpd.y);
+        dst[q + s * (4 * pp)] = make_float2(apc.x + bpd.x, apc.y + bpd.y);
+        dst[q + s * (4 * pp + 1)] = make_float2(y1.x * w1.x - y1.y * w1.y, y1.x * w1.y + y1.y * w1.x);
+        dst[q + s * (4 * pp + 2)] = make_float2(y2.x * w2.x - y2.y * w2.y, y2.x * w2.y + y2.y * w2.x);
+        dst[q + s * (4 * pp + 3)] = make_float2(y3.x * w3.x - y3.y * w3.y, y3.x * w3.y + y3.y * w3.x);
         __syncthreads();
         float2 *t = src; src = dst; dst = t;
-        n = m; s <<= 1;
+        n = m; s <<= 2;
     }
     return src;
 }
@@ -1182,6 +1189,33 @@ static int run_tiles(int tiles, size_t rows) {
     if (R < 1) R = 1;
     const int runs = (tiles + R - 1) / R;
     return (tiles + runs - 1) / runs;
+}
+
+// two order statistics of many SHORT rows (the per-bin noise floor over the frames of a chunk: hundreds of values per
+// row, hundreds of thousands of rows): one wave per row, values in LDS, every lane ranks its candidates by counting
+// (#smaller + #equal-with-lower-index gives each value a unique rank), the lanes holding ranks k_lo / k_hi write them.
+constexpr int RANK_MAX = 2048;
+
+__global__ __launch_bounds__(256) void rank_select_kernel(const float *rows, int n_rows, int F, int k_lo, int k_hi, float *out) {
+    extern __shared__ float rv[];   // [4][F]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= n_rows) return;
+    float *v = rv + (size_t)wave * F;
+    const float *src = rows + (size_t)row * F;
+    for (int i = lane; i < F; i += 64) v[i] = src[i];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (int i = lane; i < F; i += 64) {
+        const float x = v[i];
+        int rank = 0;
+        for (int m = 0; m < F; ++m) {
+            const float y = v[m];
+            rank += (y < x || (y == x && m < i)) ? 1 : 0;
+        }
+        if (rank == k_lo) out[(size_t)row * 2] = x;
+        if (rank == k_hi) out[(size_t)row * 2 + 1] = x;
+    }
 }
 
 struct wh_chanbank {
@@ -1451,8 +1485,12 @@ extern "C" int wh_chanbank_run(wh_chanbank *b, const void *d_in, size_t n_chunks
             const double virt = (double)(F - 1) * 0.1;   // np.percentile(..., 10), method 'linear'
             int k_lo = (int)floor(virt);
             int k_hi = k_lo + 1 < F ? k_lo + 1 : F - 1;
-            hipLaunchKernelGGL(select_kth_kernel, dim3((unsigned)(rows * NR_BINS), 2), dim3(256), 0, st, b->d_nr_mag, F, k_lo,
-                               k_hi, b->d_nr_sel);
+            if (F <= RANK_MAX)
+                hipLaunchKernelGGL(rank_select_kernel, dim3((unsigned)((rows * NR_BINS + 3) / 4)), dim3(256),
+                                   (size_t)4 * F * sizeof(float), st, b->d_nr_mag, (int)(rows * NR_BINS), F, k_lo, k_hi, b->d_nr_sel);
+            else
+                hipLaunchKernelGGL(select_kth_kernel, dim3((unsigned)(rows * NR_BINS), 2), dim3(256), 0, st, b->d_nr_mag, F, k_lo,
+                                   k_hi, b->d_nr_sel);
             WH_LAUNCH_CHECK();
             WH_HIP(hipMemsetAsync(b->d_fm, 0, rows * (size_t)c.chunk_len * sizeof(float), st));
             hipLaunchKernelGGL(nr_istft_kernel, dim3(F, (unsigned)rows), dim3(256), 0, st, b->d_fm, c.chunk_len, F,
