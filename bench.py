@@ -325,6 +325,21 @@ def main() -> None:
                          "kernel": "pfb1024_kernel", "kernel_ms": round(k_ms, 4),
                          "algorithmic_bytes_per_launch": BYTES_PER_SAMPLE * fused_samples},
         }
+        if world == 1:
+            # yardstick: what a plain device copy of the same read:write mix (1:2) moves on THIS box, same process
+            # (HBM efficiency differs by +-5 % between boxes; the guide's ~6.3 TB/s copy figure is a best case)
+            src = torch.empty(1 << 28, dtype=torch.float32, device="cuda").normal_()
+            dst = torch.empty(2, 1 << 28, dtype=torch.float32, device="cuda")
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for _ in range(3):
+                dst.copy_(src.expand(2, -1))
+            ev0.record()
+            for _ in range(10):
+                dst.copy_(src.expand(2, -1))
+            ev1.record()
+            torch.cuda.synchronize()
+            line["roofline"]["device_copy_yardstick_GBps"] = round(3 * 4 * (1 << 28) * 10 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9, 1)
+            del src, dst
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline()
         if world == 1 and not args.no_secondary:
