@@ -5,6 +5,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -76,3 +78,21 @@ def test_product_has_no_oracle_or_cpu_fallback():
             txt = open(os.path.join(pkg, fn)).read()
             assert "oracle" not in txt.replace("no oracle", ""), fn
             assert "ref_np" not in txt, fn
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """include/wavehip.h must be usable from plain C (C11, -pedantic): compile tests/c/abi_smoke.c with gcc, link it
+    against libwavehip.so and run it (argument-error path only: no GPU needed)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    libdir = os.path.join(ROOT, "wavecap-sdr_amd", "wavehip")
+    exe = str(tmp_path / "abi_smoke")
+    r = subprocess.run([gcc, "-std=c11", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                        "-o", exe, os.path.join(ROOT, "tests", "c", "abi_smoke.c"), "-L", libdir, "-lwavehip",
+                        f"-Wl,-rpath,{libdir}"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "wh_pfb_create" in r.stdout, (r.returncode, r.stdout, r.stderr)
