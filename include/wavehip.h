@@ -50,6 +50,10 @@ int wh_clip_f32(const float *d_in, float *d_out, size_t n, void *stream);
  * buffer: h_out[3] = {mean(x^2), max |x|, 1 if all finite else 0}.  Synchronous.                      */
 int wh_audio_stats(const float *d_x, size_t n, float *h_out, void *stream);
 
+/* noise_blanker, dsp/filters.py:267-343 (real float32): samples whose magnitude exceeds median|x| * threshold_factor
+ * (= float32(10^(threshold_db/20))) and blanking_width neighbours on each side are zeroed; d_out != d_in.        */
+int wh_noise_blanker(const float *d_x, float *d_out, size_t n, float threshold_factor, int blanking_width, void *stream);
+
 /* ---- A2: stateless NCO mix, capture.py:166-193 freq_shift -------------------------
  * phase[n] = f32(-2 pi off/fs) * f32(n) (float32 product), restarted every call.     */
 int wh_nco_mix(const float *d_iq, float *d_out, size_t n, int offset_hz, int sample_rate,

@@ -574,6 +574,26 @@ def gen_nid():
     save("nid", **out)
 
 
+def gen_blanker():
+    """A14: noise_blanker (dsp/filters.py:267-343) on float32 audio with impulses; even and odd lengths."""
+    from wavecapsdr.dsp.filters import noise_blanker
+    rng = np.random.default_rng(1500)
+    out = {}
+    for tag, n, db, w in (("even", 6000, 10.0, 3), ("odd", 4001, 8.0, 5), ("w0", 1000, 12.0, 0), ("quiet", 512, 10.0, 3)):
+        x = (0.1 * rng.standard_normal(n)).astype(np.float32)
+        idx = rng.choice(n, size=max(1, n // 200), replace=False)
+        x[idx] += rng.choice([-1.0, 1.0], size=idx.size).astype(np.float32) * rng.uniform(0.5, 3.0, idx.size).astype(np.float32)
+        x[0] = 2.0
+        x[-1] = -2.0
+        if tag == "quiet":
+            x[:] = 0
+        out[f"{tag}_in"] = x
+        out[f"{tag}_out"] = noise_blanker(x.copy(), threshold_db=db, blanking_width=w)
+        out[f"{tag}_args"] = np.array([db, w])
+    out["tags"] = np.array(["even", "odd", "w0", "quiet"])
+    save("blanker", **out)
+
+
 def gen_cqpsk():
     """A12: Phase-2 CQPSK chain (dsp/p25/cqpsk.py) and the standalone GardnerTED."""
     from wavecapsdr.dsp.p25.cqpsk import CQPSKDemodulator as RefCQPSK
@@ -704,7 +724,7 @@ def gen_lsm():
     save("lsm", **out)
 
 
-ALL = dict(nid=gen_nid, classifier=gen_classifier, recorder=gen_recorder, nr=gen_nr, sam=gen_sam, rawdig=gen_rawdig, lsm=gen_lsm, framer=gen_framer, cqpsk=gen_cqpsk, trunk=gen_trunk, a1=gen_a1, a2=gen_a2, a3=gen_a3, a6=gen_a6, chain=gen_chain, a7=gen_a7, a8=gen_a8, c4fm=gen_c4fm)
+ALL = dict(blanker=gen_blanker, nid=gen_nid, classifier=gen_classifier, recorder=gen_recorder, nr=gen_nr, sam=gen_sam, rawdig=gen_rawdig, lsm=gen_lsm, framer=gen_framer, cqpsk=gen_cqpsk, trunk=gen_trunk, a1=gen_a1, a2=gen_a2, a3=gen_a3, a6=gen_a6, chain=gen_chain, a7=gen_a7, a8=gen_a8, c4fm=gen_c4fm)
 
 if __name__ == "__main__":
     import logging

@@ -954,3 +954,19 @@ class NIDFrontEnd:
                         events.append((self.pos + i, nac, dat & 0xF, e))
         self.pos += len(dibits)
         return events
+
+
+def noise_blanker(x: np.ndarray, threshold_db: float = 10.0, blanking_width: int = 3) -> np.ndarray:
+    """dsp/filters.py:267-343: median |x| baseline, threshold in dB above it, dilated mask zeroed."""
+    if x.size == 0:
+        return x.astype(np.float32, copy=False)
+    mag = np.abs(x)
+    med = np.median(mag)
+    if med < 1e-10:
+        return x.astype(np.float32, copy=False)
+    mask = mag > med * (10 ** (threshold_db / 20.0))
+    if blanking_width > 0 and mask.any():
+        mask = np.convolve(mask.astype(np.float32), np.ones(2 * blanking_width + 1, dtype=np.float32), mode="same") > 0
+    y = x.copy()
+    y[mask] = 0
+    return y.astype(np.float32)

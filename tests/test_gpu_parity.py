@@ -789,3 +789,14 @@ def test_chain_nbfm_other_rates_vs_oracle(wh, O):
                 assert res[k][0].shape == ref.shape, (fs, k)
                 assert peak_rel_err(res[k][0], ref) <= TOL, (fs, fmt, k, peak_rel_err(res[k][0], ref))
                 assert abs(res[k][1]["rssi_db"] - met["rssi_db"]) <= 2e-4
+
+
+def test_a14_noise_blanker(wh, golden):
+    """noise_blanker (dsp/filters.py:267-343) standalone: bit-exact vs the reference (the samples kept are copied,
+    the rest are zeros); even / odd lengths (np.median's two middle values), width 0, all-zero input."""
+    g = golden("blanker")
+    for tag in [str(t) for t in g["tags"]]:
+        db, w = g[f"{tag}_args"]
+        got = wh.noise_blanker(g[f"{tag}_in"], float(db), int(w))
+        assert got.dtype == np.float32 and np.array_equal(got, g[f"{tag}_out"]), tag
+    assert wh.noise_blanker(np.array([], dtype=np.float32)).size == 0

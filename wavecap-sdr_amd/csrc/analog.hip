@@ -1565,3 +1565,52 @@ extern "C" int wh_channel_signal_metrics(const void *d_in, int input_format, siz
     WH_HIP(hipFreeAsync(d_acc, st));
     return WH_OK;
 }
+
+// ---- noise blanker (reference dsp/filters.py:267-343), real float32 rows ----------------------------------------
+// median |x| (np.median: mean of the two middle order statistics for even n, in float32) -> threshold = median *
+// float32(10^(dB/20)) -> samples above it and `width` neighbours on each side are zeroed.  The reference's
+// dispatcher never forwards enable_noise_blanker (capture.py:340-414); this is the standalone function.
+namespace {
+__global__ __launch_bounds__(256) void nb_abs_kernel(const float *x, float *mag, size_t n) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) mag[i] = fabsf(x[i]);
+}
+__global__ __launch_bounds__(256) void nb_apply_kernel(const float *x, const float *sel, float factor, int n, int width,
+                                                       int odd, float *out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float med = odd ? sel[1] : __fmul_rn(__fadd_rn(sel[0], sel[1]), 0.5f);
+    float v = x[i];
+    if (med >= 1e-10f) {
+        const float thr = __fmul_rn(med, factor);
+        bool hit = false;
+        for (int d = -width; d <= width; ++d) {
+            const int j = i + d;
+            if (j >= 0 && j < n && fabsf(x[j]) > thr) hit = true;
+        }
+        if (hit) v = 0.0f;
+    }
+    out[i] = v;
+}
+}  // namespace
+
+extern "C" int wh_noise_blanker(const float *d_x, float *d_out, size_t n, float threshold_factor, int blanking_width,
+                                void *stream) {
+    if (n == 0) return WH_OK;
+    if (!d_x || !d_out || d_x == d_out || n > ((size_t)1 << 24) || blanking_width < 0 || blanking_width > 4096)
+        return set_err(WH_E_ARG, "wh_noise_blanker: bad arguments (out of place, n <= 2^24)");
+    hipStream_t st = as_stream(stream);
+    float *d_mag = nullptr, *d_sel = nullptr;
+    WH_HIP(hipMallocAsync(reinterpret_cast<void **>(&d_mag), n * sizeof(float), st));
+    WH_HIP(hipMallocAsync(reinterpret_cast<void **>(&d_sel), 2 * sizeof(float), st));
+    hipLaunchKernelGGL(nb_abs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_x, d_mag, n);
+    const int k_hi = (int)(n / 2), k_lo = (n & 1) ? k_hi : k_hi - 1;
+    hipLaunchKernelGGL(select_kth_kernel, dim3(1, 2), dim3(256), 0, st, d_mag, (int)n, k_lo, k_hi, d_sel);
+    hipLaunchKernelGGL(nb_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_x, d_sel, threshold_factor,
+                       (int)n, blanking_width, (int)(n & 1), d_out);
+    hipError_t e = hipGetLastError();
+    (void)hipFreeAsync(d_mag, st);
+    (void)hipFreeAsync(d_sel, st);
+    if (e != hipSuccess) return set_err(WH_E_HIP, "wh_noise_blanker: %s", hipGetErrorString(e));
+    return WH_OK;
+}

@@ -87,6 +87,7 @@ PROTOTYPES = {
     "wh_bch_decode": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wh_bch_destroy": (None, [c_void_p]),
     "wh_binstats_update": (c_int, [c_void_p, c_size_t, c_int, c_void_p, c_void_p]),
+    "wh_noise_blanker": (c_int, [c_void_p, c_void_p, c_size_t, c_float, c_int, c_void_p]),
     "wh_audio_stats": (c_int, [c_void_p, c_size_t, C.POINTER(c_float), c_void_p]),
     "wh_nco_mix": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
     "wh_fm_discriminate": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),

@@ -536,3 +536,19 @@ class ChannelDispatcher:
                 for i, r in zip(idx, bank.collect(audio, met)):
                     results[i] = r
         return results
+
+
+def noise_blanker(x, threshold_db: float = 10.0, blanking_width: int = 3) -> np.ndarray:
+    """dsp/filters.py:267-343 for real float32 signals (the form every demodulator calls it in).  The reference's
+    dispatcher never forwards `enable_noise_blanker`, so ChannelBank ignores that flag like the reference does; this
+    is the standalone function."""
+    torch = _lib.require_gpu()
+    a = np.ascontiguousarray(x, dtype=np.float32)
+    if a.size == 0:
+        return a
+    d = torch.from_numpy(a).cuda()
+    out = torch.empty_like(d)
+    factor = float(np.float32(10 ** (threshold_db / 20.0)))
+    _lib.check(_lib.lib.wh_noise_blanker(d.data_ptr(), out.data_ptr(), a.size, factor, int(blanking_width),
+                                         _lib.stream_ptr(torch)), "wh_noise_blanker")
+    return out.cpu().numpy()
