@@ -800,3 +800,18 @@ def test_a14_noise_blanker(wh, golden):
         got = wh.noise_blanker(g[f"{tag}_in"], float(db), int(w))
         assert got.dtype == np.float32 and np.array_equal(got, g[f"{tag}_out"]), tag
     assert wh.noise_blanker(np.array([], dtype=np.float32)).size == 0
+
+
+def test_chain_small_and_odd_chunk_lengths(wh, O):
+    """Short / awkward chunk lengths through every row form (fused FM tiles larger than the chunk, IIR tiles of one
+    partial 64-sample block, resampler output shorter than its taps): still the oracle's numbers."""
+    fs = 2_400_000
+    for n in (50, 63, 64, 65, 1000, 4097):
+        iq = S.fm_tone_c64(n, fs, seed=700 + n, audio_hz=20_000.0, deviation=50_000.0, carrier_hz=100e3, noise_amp=0.05)
+        a, m = wh.process_channel_dsp_stateless(iq, fs, _nbfm_cfg(wh, 100e3))
+        ref, met = O.process_channel_nbfm(iq, fs, 100e3)
+        assert a.shape == ref.shape and peak_rel_err(a, ref) <= TOL, ("nbfm", n, peak_rel_err(a, ref))
+        a, m = wh.process_channel_dsp_stateless(iq, fs, wh.ChannelConfig(mode="wbfm", offset_hz=100e3))
+        ref, met = O.process_channel_wbfm(iq, fs, 100e3)
+        assert a.shape == ref.shape and peak_rel_err(a, ref) <= TOL, ("wbfm", n, peak_rel_err(a, ref))
+        assert abs(m["rssi_db"] - met["rssi_db"]) <= 2e-4
