@@ -249,6 +249,8 @@ struct PfbGenArgs {
     const float *arms;   // float32 [M][T]
     const float2 *tw;    // exp(-2 pi i m / M), m in [0, M)
     int M, T, log2M;     // log2M = 0 when M is not a power of two
+    int n_radix;         // > 0: M = product of radix[0..n_radix), each in {2, 3, 4, 5}: mixed-radix Stockham
+    int radix[16];
     long long hop0;      // first hop of range A (blocks [0, n_hops))
     long long n_hops;
     long long hop0b;     // first hop of range B (blocks [n_hops, n_hops + n_hops_b)); lets the head
@@ -279,7 +281,64 @@ __global__ __launch_bounds__(256) void pfb_generic_kernel(PfbGenArgs a) {
     }
     __syncthreads();
     float2 *o = a.out + (size_t)h * M;
-    if (a.log2M > 0) {
+    if (a.n_radix > 0) {
+        // Stockham autosort, mixed radix (DIF), ping-pong between sm[0:M) and sm[M:2M): a pass of radix r with
+        // sub-length n and stride s (n*s = M), m = n/r: for p < m, q < s
+        //   y[q + s*(r*p + k)] = (sum_j x[q + s*(p + j*m)] * W_r^(j*k)) * W_n^(p*k),   W_n^(p*k) = tw[(p*k*s) mod M]
+        float2 *src = sm, *dst = sm + M;
+        int n = M, s = 1;
+        for (int st = 0; st < a.n_radix; ++st) {
+            const int r = a.radix[st];
+            const int m = n / r;
+            for (int i = threadIdx.x; i < M / r; i += blockDim.x) {
+                const int pp = i / s, q = i - pp * s;
+                const float2 *x = src + q + s * pp;
+                float2 *y = dst + q + s * r * pp;
+                const int sm_ = s * m;
+                const int tws = pp * s;   // k * tws < M for k < r: no wrap
+                if (r == 2) {
+                    float2 c0 = x[0], c1 = x[sm_];
+                    y[0] = cadd(c0, c1);
+                    y[s] = cmul(csub(c0, c1), a.tw[tws]);
+                } else if (r == 4) {
+                    float2 v0 = x[0], v1 = x[sm_], v2 = x[2 * sm_], v3 = x[3 * sm_];
+                    fft4(v0, v1, v2, v3);
+                    y[0] = v0;
+                    y[s] = cmul(v1, a.tw[tws]);
+                    y[2 * s] = cmul(v2, a.tw[2 * tws]);
+                    y[3 * s] = cmul(v3, a.tw[3 * tws]);
+                } else if (r == 3) {
+                    const float C = -0.5f, S = -0.86602540378443864676f;   // exp(-2 pi i / 3)
+                    float2 v0 = x[0], v1 = x[sm_], v2 = x[2 * sm_];
+                    float2 t1 = cadd(v1, v2), t2 = csub(v1, v2);
+                    float2 u = make_float2(fmaf(C, t1.x, v0.x), fmaf(C, t1.y, v0.y));
+                    float2 w = make_float2(-S * t2.y, S * t2.x);            // i * S * t2
+                    y[0] = cadd(v0, t1);
+                    y[s] = cmul(cadd(u, w), a.tw[tws]);
+                    y[2 * s] = cmul(csub(u, w), a.tw[2 * tws]);
+                } else {   // r == 5
+                    const float C1 = 0.30901699437494742410f, S1 = 0.95105651629515357212f;    // cos, sin 2 pi / 5
+                    const float C2 = -0.80901699437494742410f, S2 = 0.58778525229247312917f;   // cos, sin 4 pi / 5
+                    float2 v0 = x[0], v1 = x[sm_], v2 = x[2 * sm_], v3 = x[3 * sm_], v4 = x[4 * sm_];
+                    float2 a1 = cadd(v1, v4), b1 = csub(v1, v4), a2 = cadd(v2, v3), b2 = csub(v2, v3);
+                    float2 r1 = make_float2(v0.x + C1 * a1.x + C2 * a2.x, v0.y + C1 * a1.y + C2 * a2.y);
+                    float2 r2 = make_float2(v0.x + C2 * a1.x + C1 * a2.x, v0.y + C2 * a1.y + C1 * a2.y);
+                    // -i (S1 b1 + S2 b2), -i (S2 b1 - S1 b2)   (forward transform)
+                    float2 i1 = make_float2(S1 * b1.y + S2 * b2.y, -(S1 * b1.x + S2 * b2.x));
+                    float2 i2 = make_float2(S2 * b1.y - S1 * b2.y, -(S2 * b1.x - S1 * b2.x));
+                    y[0] = make_float2(v0.x + a1.x + a2.x, v0.y + a1.y + a2.y);
+                    y[s] = cmul(cadd(r1, i1), a.tw[tws]);
+                    y[2 * s] = cmul(cadd(r2, i2), a.tw[2 * tws]);
+                    y[3 * s] = cmul(csub(r2, i2), a.tw[3 * tws]);
+                    y[4 * s] = cmul(csub(r1, i1), a.tw[4 * tws]);
+                }
+            }
+            __syncthreads();
+            float2 *tmp = src; src = dst; dst = tmp;
+            n = m; s *= r;
+        }
+        for (int k = threadIdx.x; k < M; k += blockDim.x) o[k] = src[k];
+    } else if (a.log2M > 0) {
         // Stockham autosort radix-2 (DIF), ping-pong between sm[0:M) and sm[M:2M):
         // stage with sub-length n and stride s (n*s = M): for p < n/2, q < s
         //   y[q + s*2p] = a + b ; y[q + s*(2p+1)] = (a - b) * exp(-2 pi i p/n)
@@ -498,7 +557,23 @@ static int launch_generic(wh_pfb *p, const void *d_iq, int fmt, float *d_out, lo
     a.M = p->M; a.T = p->T; a.log2M = p->log2M;
     a.hop0 = hop0; a.n_hops = n_hops;
     a.hop0b = hop0b; a.n_hops_b = n_hops_b;
-    size_t smem = (size_t)p->M * sizeof(float2) * (p->log2M ? 2 : 1);
+    // factor M into radices 4, 2, 3, 5 (mixed-radix Stockham); anything else falls back to the direct DFT
+    a.n_radix = 0;
+    {
+        int rem = p->M, k = 0;
+        int rad[16];
+        while (rem % 4 == 0 && k < 16) { rad[k++] = 4; rem /= 4; }
+        while (rem % 2 == 0 && k < 16) { rad[k++] = 2; rem /= 2; }
+        while (rem % 3 == 0 && k < 16) { rad[k++] = 3; rem /= 3; }
+        while (rem % 5 == 0 && k < 16) { rad[k++] = 5; rem /= 5; }
+        if (rem == 1 && k > 0 && !getenv("WH_PFB_NO_MIXED_RADIX")) {
+            a.n_radix = k;
+            for (int i = 0; i < 16; ++i) a.radix[i] = i < k ? rad[i] : 1;
+        } else {
+            for (int i = 0; i < 16; ++i) a.radix[i] = 1;
+        }
+    }
+    size_t smem = (size_t)p->M * sizeof(float2) * ((p->log2M || a.n_radix) ? 2 : 1);
     if (smem > 64 * 1024) {
         WH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pfb_generic_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
