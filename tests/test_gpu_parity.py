@@ -815,3 +815,20 @@ def test_chain_small_and_odd_chunk_lengths(wh, O):
         ref, met = O.process_channel_wbfm(iq, fs, 100e3)
         assert a.shape == ref.shape and peak_rel_err(a, ref) <= TOL, ("wbfm", n, peak_rel_err(a, ref))
         assert abs(m["rssi_db"] - met["rssi_db"]) <= 2e-4
+
+
+@pytest.mark.parametrize("fs,bw,M", [(8_000_000, 25_000, 320), (2_400_000, 12_500, 192), (6_000_000, 12_500, 480),
+                                      (10_000_000, 12_500, 800), (2_400_000, 25_000, 96), (1_000_000, 62_500, 16),
+                                      (2_800_000, 100_000, 28)])
+def test_a7_pfb_other_channel_counts_vs_oracle(wh, O, fs, bw, M):
+    """The generic path for the channel counts other sample-rate / spacing pairs give: mixed-radix Stockham passes of
+    radix 4, 2, 3 and 5 (M = 320 is the reference's own benchmark_dsp.py shape), and the direct-DFT fallback for a
+    count with another prime factor (28 = 4 * 7); two calls so the carried history is exercised."""
+    ch = wh.PolyphaseChannelizer(fs, bw)
+    ref = O.PolyphaseChannelizer(fs, bw)
+    assert ch.channel_count == M == ref.channel_count
+    x = S.noise_c64(M * 120 + 17, 780 + M)
+    for part in (x[:M * 70 + 5], x[M * 70 + 5:]):
+        a, b = ch.process(part), ref.process(part)
+        assert a.shape == b.shape and peak_rel_err(a, b) <= TOL, (M, peak_rel_err(a, b))
+    assert np.array_equal(ch.arm_history, ref.arm_history)
