@@ -122,6 +122,35 @@ def secondary_pfb_int16(torch, steps: int = 10):
             "frac_of_8TBps": round(20.0 * n / k / 1e6 / 8000.0, 4)}
 
 
+def secondary_pfb_m320(torch, steps: int = 5):
+    """The channelizer shape of the reference's own benchmark_dsp.py:112-141 (8 MS/s, 25 kHz spacing -> M = 320,
+    generic mixed-radix path) beside the CPU oracle on the same shape."""
+    import numpy as np
+    import signals as S
+    import wavehip
+    from oracle import ref_np as O
+
+    fs, bw, n = 8_000_000, 25_000, 1 << 24
+    ch = wavehip.PolyphaseChannelizer(fs, bw)
+    x = torch.view_as_complex(torch.randn(n, 2, device="cuda").mul_(0.5))
+    out = torch.empty((ch.hops(n), ch.channel_count), dtype=torch.complex64, device="cuda")
+    ch.process_device(x, out)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ch.process_device(x, out)
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / steps
+    ref = O.PolyphaseChannelizer(fs, bw)
+    xc = S.noise_c64(1 << 20, 4)
+    t0 = time.perf_counter()
+    ref.process(xc)
+    cpu = (1 << 20) / (time.perf_counter() - t0) / 1e6
+    return {"workload": "320-channel filterbank, 8 MS/s cf32 (benchmark_dsp.py shape), 2^24 samples per call",
+            "input_msps": round(n / el / 1e6, 1), "x_realtime": round(n / el / fs, 1),
+            "cpu_port_input_msps": round(cpu, 2), "cpu_cores": 1}
+
+
 def secondary_wbfm(torch, steps: int = 10):
     """BASELINE configs[0]: ONE default WBFM channel on a 2.4 MS/s complex64 stream, one 120 000-sample chunk per
     call (the live shape: host buffer in, audio out), beside the CPU oracle on the same chunk."""
@@ -345,7 +374,8 @@ def main() -> None:
         if world == 1 and not args.no_secondary:
             del x, out
             torch.cuda.empty_cache()
-            line["secondary"] = {"pfb_int16": secondary_pfb_int16(torch), "wbfm_single": secondary_wbfm(torch),
+            line["secondary"] = {"pfb_int16": secondary_pfb_int16(torch), "pfb_m320": secondary_pfb_m320(torch),
+                                 "wbfm_single": secondary_wbfm(torch),
                                  "nbfm_bank": secondary_nbfm(torch),
                                  "c4fm_bank": secondary_c4fm(torch)}
         print(json.dumps(line), flush=True)
