@@ -2,7 +2,8 @@
 """Kernel-variant sweep for the fused filterbank (diagnostics; interleaved rounds in ONE process).
 usage: python tools/pfb_sweep.py "variant,gpw,ablate" ...   e.g.  1,16,0 1,32,0 1,32,1
 (variant is kept in the tuple for log compatibility; only the run length WH_PFB_GPW and the
-diagnostic WH_PFB_ABLATE (1 = no stores, 2 = no input reads) are live knobs)"""
+diagnostic WH_PFB_ABLATE (1 = no stores) are live knobs; a read-suppression knob (2) was used once for the ablation
+in DESIGN.md and removed again: the extra branch in the prefetch loop de-batched the int16 variant's loads)"""
 import os, sys, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "wavecap-sdr_amd")]

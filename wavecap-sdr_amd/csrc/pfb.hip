@@ -149,11 +149,6 @@ __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
             const long long xn = (h + GH + 1) * FHOP + t;
 #pragma unroll
             for (int i = 0; i < GH; ++i) {
-                if (a.ablate == 2) {   // diagnostics: no input reads
-                    wA[9 + i] = make_float2(0.25f, -0.5f);
-                    wB[9 + i] = make_float2(0.5f, 0.25f);
-                    continue;
-                }
                 wA[9 + i] = ld_iq<FMT>(a.x, xn + i * FHOP);
                 wB[9 + i] = ld_iq<FMT>(a.x, xn + i * FHOP + 256);
             }
