@@ -573,10 +573,14 @@ static int launch_generic(wh_pfb *p, const void *d_iq, int fmt, float *d_out, lo
         WH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pfb_generic_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     }
+    // block size: small channel counts are latency-bound per workgroup (a few hundred points, barriers between
+    // passes), so fewer threads per hop and more hops in flight per CU win; WH_PFB_GEN_THREADS overrides
+    int bt = p->M <= 512 ? 64 : 256;
+    if (const char *e = getenv("WH_PFB_GEN_THREADS")) { int v = atoi(e); if (v == 64 || v == 128 || v == 256) bt = v; }
     // grid.x is limited to 2^31-1; chunk very long tails (never happens for the fast path)
     const long long MAXG = 1 << 30;
     if (n_hops_b > 0) {   // two short ranges in one launch
-        hipLaunchKernelGGL(pfb_generic_kernel, dim3((unsigned)(n_hops + n_hops_b)), dim3(256), smem, st, a);
+        hipLaunchKernelGGL(pfb_generic_kernel, dim3((unsigned)(n_hops + n_hops_b)), dim3(bt), smem, st, a);
         WH_LAUNCH_CHECK();
         return WH_OK;
     }
@@ -584,7 +588,7 @@ static int launch_generic(wh_pfb *p, const void *d_iq, int fmt, float *d_out, lo
         long long cnt = n_hops - off < MAXG ? n_hops - off : MAXG;
         a.hop0 = hop0 + off;
         a.n_hops = cnt;
-        hipLaunchKernelGGL(pfb_generic_kernel, dim3((unsigned)cnt), dim3(256), smem, st, a);
+        hipLaunchKernelGGL(pfb_generic_kernel, dim3((unsigned)cnt), dim3(bt), smem, st, a);
         WH_LAUNCH_CHECK();
     }
     return WH_OK;
