@@ -832,3 +832,24 @@ def test_a7_pfb_other_channel_counts_vs_oracle(wh, O, fs, bw, M):
         a, b = ch.process(part), ref.process(part)
         assert a.shape == b.shape and peak_rel_err(a, b) <= TOL, (M, peak_rel_err(a, b))
     assert np.array_equal(ch.arm_history, ref.arm_history)
+
+
+def test_operator_from_a_thread_pool(wh, golden):
+    """The reference calls _process_channel_dsp_stateless from a ThreadPoolExecutor(max_workers=3)
+    (capture.py:1906-1925, 2521-2567): the drop-in must give the same results when 3 threads hammer it with
+    different channels of the same chunk (shared bank cache, per-bank workspace)."""
+    from concurrent.futures import ThreadPoolExecutor
+    g = golden("chain_analog")
+    fs, n, seed0 = (int(v) for v in g["nbfm_args"])
+    offs = S.nbfm_bank_offsets()
+    z = wh.unpack_iq16(S.pack_iq16_np(S.nbfm_bank_c64(n, fs, seed=seed0, start=0)))
+    ks = [0, 13, 31, 5, 20, 13, 0, 31]
+    serial = [wh.process_channel_dsp_stateless(z, fs, _nbfm_cfg(wh, offs[k])) for k in ks]
+    with ThreadPoolExecutor(max_workers=3) as ex:
+        for _ in range(3):
+            par = list(ex.map(lambda k: wh.process_channel_dsp_stateless(z, fs, _nbfm_cfg(wh, offs[k])), ks))
+            for a, b in zip(serial, par):
+                assert np.array_equal(a[0], b[0]) and a[1] == b[1]
+    for k, r in zip(ks, serial):
+        if k in (0, 13, 31):
+            assert peak_rel_err(r[0], g[f"nbfm0_k{k}_audio"]) <= TOL

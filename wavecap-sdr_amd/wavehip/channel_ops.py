@@ -23,6 +23,7 @@ from __future__ import annotations
 
 import ctypes as C
 import logging
+import threading
 from dataclasses import dataclass, field
 from math import gcd
 from typing import Any
@@ -421,7 +422,8 @@ def update_signal_metrics(samples, sample_rate: int, offsets_hz, input_format: s
     return res
 
 
-_bank_cache: dict[tuple, ChannelBank] = {}
+_bank_cache: dict[tuple, tuple] = {}
+_bank_cache_lock = threading.Lock()     # the reference calls the operator from a 3-thread pool (capture.py:1906-1925)
 
 DIGITAL_MODES = ("p25", "dmr", "nxdn", "dstar", "ysf")      # capture.py:424
 
@@ -471,12 +473,15 @@ def process_channel_dsp_stateless(samples, sample_rate: int, cfg) -> tuple[np.nd
     if why:
         raise NotImplementedError(f"wavehip: {why} is not implemented on the device")
     key = (int(sample_rate), int(samples.shape[0]), int(round(float(cfg.offset_hz)))) + _chain_key(cfg)
-    bank = _bank_cache.get(key)
-    if bank is None:
-        if len(_bank_cache) >= 64:
-            _bank_cache.pop(next(iter(_bank_cache)))
-        bank = _bank_cache[key] = ChannelBank(sample_rate, samples.shape[0], [cfg])
-    return bank.process(samples)[0]
+    with _bank_cache_lock:
+        entry = _bank_cache.get(key)
+        if entry is None:
+            if len(_bank_cache) >= 64:
+                _bank_cache.pop(next(iter(_bank_cache)))      # the evicted bank lives on while a thread still holds it
+            entry = _bank_cache[key] = (ChannelBank(sample_rate, samples.shape[0], [cfg]), threading.Lock())
+    bank, lock = entry
+    with lock:                                                # a bank owns one workspace: one call at a time
+        return bank.process(samples)[0]
 
 
 class ChannelDispatcher:
