@@ -324,6 +324,24 @@ def main() -> None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # outside the timed region: latency of one synchronous scanner/activity exchange
+    reduce_ms = None
+    if world > 1:
+        try:
+            st = stats2[0] if not rehearsal else stats2[0].cpu()
+            for _ in range(3):
+                reduce_channel_stats(st)
+            if not rehearsal:
+                torch.cuda.synchronize()
+            dist.barrier()
+            t1 = time.perf_counter()
+            for _ in range(20):
+                reduce_channel_stats(st)
+            if not rehearsal:
+                torch.cuda.synchronize()
+            reduce_ms = (time.perf_counter() - t1) / 20 * 1e3
+        except Exception as e:      # never let the side measurement take the bench line down
+            print(f"[bench] scanner reduce timing skipped: {e}", file=sys.stderr)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -347,7 +365,8 @@ def main() -> None:
                                    f"2^{args.log2n} samples per step per GPU, one stream per GPU "
                                    "(BASELINE.json configs[2] / configs[4])",
                        "samples_per_step_per_gpu": n, "hops_per_step": hops, "channels": M,
-                       "scan_window_hops": scan, "collective": "rccl all_gather(stats 40 KB/GPU), async, 1 per step" if world > 1 else "none"},
+                       "scan_window_hops": scan, "collective": "rccl all_gather(stats 40 KB/GPU), async, 1 per step" if world > 1 else "none",
+                       "scanner_reduce_ms": None if reduce_ms is None else round(reduce_ms, 4)},
             "input_msps": round(world * n * args.steps / elapsed / 1e6, 1),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
