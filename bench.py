@@ -95,6 +95,11 @@ def secondary_nbfm(torch, steps: int = 5):
             "value": round(msps * K, 1), "unit": "MS/s x channels", "input_msps": round(msps, 1),
             "ms_per_launch": round(el * 1e3, 3), "x_realtime": round(msps / 2.4, 1),
             "algorithmic_GBps": round(6.56 * msps / 1e3, 2),
+            # the second roofline of this config ("report it against both"): VALU issue.  1.036e9 wave64
+            # VALU instructions per launch (profiles/r01_pmc_sq_nbfm.txt, SQ_INSTS_VALU of the shipped kernel), 4 cycles
+            # each on one of 1024 SIMDs at 2.4 GHz
+            "valu_issue_floor_ms": round(1.036e9 * 4 / 1024 / 2.4e9 * 1e3, 3),
+            "frac_of_valu_issue": round(1.036e9 * 4 / 1024 / 2.4e9 / el, 4),
             "cpu_port_msps_x_channels": round(cpu, 2), "cpu_cores": 1}
 
 
