@@ -372,6 +372,269 @@ __global__ __launch_bounds__(256) void pfb_generic_kernel(PfbGenArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// run path: any M with 4 | M, 64 <= M <= 512, T = 9 (the reference's benchmark_dsp.py shape is M = 320)
+// ------------------------------------------------------------------------------------------
+// One WAVE walks a run of consecutive hops (4 independent waves per workgroup; no workgroup barrier in the loop).
+// Lane l owns the "quads" u = l + 64 c (c < CPL, u < M/4), i.e. the columns u, u + M/4, u + M/2, u + 3M/4:
+//   * arm MAC as in the M = 1024 kernel: two sliding register windows per quad (columns u and u + M/4 of the
+//     half-block serve all four columns because block_g[k + M/2] == block_{g+1}[k]); every input sample is
+//     loaded once per wave; the 36 taps of a quad are staged in LDS ([tap][quad] so a wave's read is contiguous);
+//   * the first Stockham pass (radix 4, stride 1) needs exactly the four values the lane holds -> in registers;
+//   * the remaining passes run in place in the wave's own LDS image: every lane reads the inputs of all its
+//     butterflies before any lane writes (one instruction stream, in-order LDS), so no ping-pong image and no
+//     s_barrier; the last pass stores straight to HBM (stride M/r: whole 512-byte rows per store).
+// Same pass plan and arithmetic as pfb_generic_kernel, which still does the first T-1 hops (carried history).
+constexpr int RT = 9;
+struct PfbRunArgs {
+    const void *x;
+    float2 *out;
+    const float *arms;     // float32 [M][9]
+    const float2 *tw;      // exp(-2 pi i m / M)
+    int M, n_radix;        // radix[0] == 4 (register pass)
+    int radix[12];
+    int stride[12];        // s of pass st (product of the earlier radices)
+    float inv_stride[12];
+    long long first_hop, end_hop;
+    long long max_block;   // last half-block index fully inside the input
+    int hops_per_wave;
+};
+
+template <int CPL>
+__device__ __forceinline__ void run_fft_passes(float2 *img, const float2 *twl, const PfbRunArgs &a, float2 *o,
+                                               int lane) {
+    const int M = a.M;
+    for (int st = 1; st < a.n_radix; ++st) {
+        const int r = a.radix[st], s = a.stride[st];
+        const float inv_s = a.inv_stride[st];
+        const int cnt = M / r;               // butterflies of this pass; input j of butterfly i is img[i + j*cnt]
+        const bool last = st == a.n_radix - 1;
+        float2 *d = last ? o : img;
+        // ps = s * floor(i / s): output base = i + (r-1)*ps, twiddle W_M^(k*ps)
+#define WH_PS(i) ((int)(((float)(i) + 0.5f) * inv_s) * s)
+        if (r == 4) {
+            float2 v[CPL][4];
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const int i = lane + 64 * c, ii = i < cnt ? i : 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[c][j] = img[ii + j * cnt];
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const int i = lane + 64 * c;
+                if (i < cnt) {
+                    fft4(v[c][0], v[c][1], v[c][2], v[c][3]);
+                    if (last) {
+                        d[i] = v[c][0]; d[i + s] = v[c][1]; d[i + 2 * s] = v[c][2]; d[i + 3 * s] = v[c][3];
+                    } else {
+                        const int ps = WH_PS(i);
+                        float2 *y = d + i + 3 * ps;
+                        y[0] = v[c][0];
+                        y[s] = cmul(v[c][1], twl[ps]);
+                        y[2 * s] = cmul(v[c][2], twl[2 * ps]);
+                        y[3 * s] = cmul(v[c][3], twl[3 * ps]);
+                    }
+                }
+            }
+        } else if (r == 2) {
+            constexpr int R = 2 * CPL;
+            float2 v[R][2];
+#pragma unroll
+            for (int c = 0; c < R; ++c) {
+                const int i = lane + 64 * c, ii = i < cnt ? i : 0;
+                v[c][0] = img[ii];
+                v[c][1] = img[ii + cnt];
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int c = 0; c < R; ++c) {
+                const int i = lane + 64 * c;
+                if (i < cnt) {
+                    const int ps = last ? 0 : WH_PS(i);
+                    float2 *y = d + i + ps;
+                    y[0] = cadd(v[c][0], v[c][1]);
+                    y[s] = cmul(csub(v[c][0], v[c][1]), twl[ps]);
+                }
+            }
+        } else if (r == 3) {
+            constexpr int R = (4 * CPL + 2) / 3;
+            const float C = -0.5f, S = -0.86602540378443864676f;   // exp(-2 pi i / 3)
+            float2 v[R][3];
+#pragma unroll
+            for (int c = 0; c < R; ++c) {
+                const int i = lane + 64 * c, ii = i < cnt ? i : 0;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) v[c][j] = img[ii + j * cnt];
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int c = 0; c < R; ++c) {
+                const int i = lane + 64 * c;
+                if (i < cnt) {
+                    const int ps = last ? 0 : WH_PS(i);
+                    float2 v0 = v[c][0], v1 = v[c][1], v2 = v[c][2];
+                    float2 t1 = cadd(v1, v2), t2 = csub(v1, v2);
+                    float2 u = make_float2(fmaf(C, t1.x, v0.x), fmaf(C, t1.y, v0.y));
+                    float2 w = make_float2(-S * t2.y, S * t2.x);            // i * S * t2
+                    float2 *y = d + i + 2 * ps;
+                    y[0] = cadd(v0, t1);
+                    y[s] = cmul(cadd(u, w), twl[ps]);
+                    y[2 * s] = cmul(csub(u, w), twl[2 * ps]);
+                }
+            }
+        } else {   // r == 5
+            constexpr int R = (4 * CPL + 4) / 5;
+            const float C1 = 0.30901699437494742410f, S1 = 0.95105651629515357212f;    // cos, sin 2 pi / 5
+            const float C2 = -0.80901699437494742410f, S2 = 0.58778525229247312917f;   // cos, sin 4 pi / 5
+            float2 v[R][5];
+#pragma unroll
+            for (int c = 0; c < R; ++c) {
+                const int i = lane + 64 * c, ii = i < cnt ? i : 0;
+#pragma unroll
+                for (int j = 0; j < 5; ++j) v[c][j] = img[ii + j * cnt];
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int c = 0; c < R; ++c) {
+                const int i = lane + 64 * c;
+                if (i < cnt) {
+                    const int ps = last ? 0 : WH_PS(i);
+                    float2 v0 = v[c][0], v1 = v[c][1], v2 = v[c][2], v3 = v[c][3], v4 = v[c][4];
+                    float2 a1 = cadd(v1, v4), b1 = csub(v1, v4), a2 = cadd(v2, v3), b2 = csub(v2, v3);
+                    float2 r1 = make_float2(v0.x + C1 * a1.x + C2 * a2.x, v0.y + C1 * a1.y + C2 * a2.y);
+                    float2 r2 = make_float2(v0.x + C2 * a1.x + C1 * a2.x, v0.y + C2 * a1.y + C1 * a2.y);
+                    float2 i1 = make_float2(S1 * b1.y + S2 * b2.y, -(S1 * b1.x + S2 * b2.x));
+                    float2 i2 = make_float2(S2 * b1.y - S1 * b2.y, -(S2 * b1.x - S1 * b2.x));
+                    float2 *y = d + i + 4 * ps;
+                    y[0] = make_float2(v0.x + a1.x + a2.x, v0.y + a1.y + a2.y);
+                    y[s] = cmul(cadd(r1, i1), twl[ps]);
+                    y[2 * s] = cmul(cadd(r2, i2), twl[2 * ps]);
+                    y[3 * s] = cmul(csub(r2, i2), twl[3 * ps]);
+                    y[4 * s] = cmul(csub(r1, i1), twl[4 * ps]);
+                }
+            }
+        }
+#undef WH_PS
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int FMT, int CPL, int GH>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CPL == 1 ? 1 : 2, CPL == 1 ? 4 : 2))) void pfb_run_kernel(PfbRunArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float2 sm[];
+    const int M = a.M, Q = M >> 2, HB = M >> 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float2 *twl = sm;                                           // [M]
+    float *tapl = reinterpret_cast<float *>(sm + M);            // [36][CPL*64]
+    float2 *img = sm + M + CPL * 64 * 18 + wave * GH * M;       // GH images of M per wave
+
+    for (int i = threadIdx.x; i < M; i += 256) twl[i] = a.tw[i];
+    for (int i = threadIdx.x; i < 36 * CPL * 64; i += 256) {
+        const int e = i / (CPL * 64), u = i - e * (CPL * 64);   // e = qq*9 + j
+        const int qq = e / RT, j = e - qq * RT;
+        tapl[i] = u < Q ? a.arms[(size_t)(u + qq * Q) * RT + j] : 0.f;
+    }
+    __syncthreads();
+
+    const long long wid = (long long)blockIdx.x * 4 + wave;
+    long long h = a.first_hop + wid * a.hops_per_wave;
+    long long h1 = h + a.hops_per_wave;
+    if (h1 > a.end_hop) h1 = a.end_hop;
+    if (h >= h1) return;
+
+    int ue[CPL];            // clamped quad index (idle lanes of a partial round recompute quad Q-1, stores masked)
+    float2 tw1[CPL], tw2[CPL], tw3[CPL];
+    float2 wA[CPL][RT + GH], wB[CPL][RT + GH];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        const int u = lane + 64 * c;
+        ue[c] = u < Q ? u : Q - 1;
+        tw1[c] = a.tw[ue[c]]; tw2[c] = a.tw[2 * ue[c]]; tw3[c] = a.tw[3 * ue[c]];
+#pragma unroll
+        for (int i = 0; i < RT + GH; ++i) {
+            long long g = h - 8 + i;
+            if (g > a.max_block) g = a.max_block;
+            wA[c][i] = ld_iq<FMT>(a.x, g * HB + ue[c]);
+            wB[c][i] = ld_iq<FMT>(a.x, g * HB + ue[c] + Q);
+            __builtin_amdgcn_sched_barrier(0);   // address, load, next: not 2 x 11 x CPL 64-bit addresses up front
+        }
+    }
+
+    for (; h < h1; h += GH) {
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            // tap-outer order: 4 taps live at a time (all 36 would cost a wave of occupancy); the accumulation order
+            // per output (j ascending) is unchanged
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            v2f y[GH][4];
+#pragma unroll
+            for (int i = 0; i < GH; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) y[i][q] = v2f{0.f, 0.f};
+            const float *tq = tapl + 64 * c + lane;
+            // (re, im) x tap as one packed FMA with the tap broadcast: written with vector types so that the
+            // compiler does not pair unrelated scalars (which costs a second, swapped copy of all 36 taps)
+#define WH_V2(f) (v2f{(f).x, (f).y})
+#pragma unroll
+            for (int j = 0; j < RT; ++j) {
+                // two-quad form: taps in two batches (the LDS reads may not cross the asm), or a quad's 36 taps plus
+                // their even-register copies overflow the 3-waves-per-SIMD budget
+                if (CPL > 1 && j == 5) asm volatile("" ::: "memory");
+                const float t0 = tq[j * (CPL * 64)], t1 = tq[(RT + j) * (CPL * 64)];
+                const float t2 = tq[(2 * RT + j) * (CPL * 64)], t3 = tq[(3 * RT + j) * (CPL * 64)];
+#pragma unroll
+                for (int i = 0; i < GH; ++i) {
+                    y[i][0] = __builtin_elementwise_fma(WH_V2(wA[c][i + 8 - j]), v2f{t0, t0}, y[i][0]);
+                    y[i][1] = __builtin_elementwise_fma(WH_V2(wB[c][i + 8 - j]), v2f{t1, t1}, y[i][1]);
+                    y[i][2] = __builtin_elementwise_fma(WH_V2(wA[c][i + 9 - j]), v2f{t2, t2}, y[i][2]);
+                    y[i][3] = __builtin_elementwise_fma(WH_V2(wB[c][i + 9 - j]), v2f{t3, t3}, y[i][3]);
+                }
+            }
+#undef WH_V2
+#pragma unroll
+            for (int i = 0; i < GH; ++i) {
+                float2 y0 = make_float2(y[i][0].x, y[i][0].y), y1 = make_float2(y[i][1].x, y[i][1].y);
+                float2 y2 = make_float2(y[i][2].x, y[i][2].y), y3 = make_float2(y[i][3].x, y[i][3].y);
+                fft4(y0, y1, y2, y3);
+                y1 = cmul(y1, tw1[c]);
+                y2 = cmul(y2, tw2[c]);
+                y3 = cmul(y3, tw3[c]);
+                if (lane + 64 * c < Q) {
+                    float4 *dst = reinterpret_cast<float4 *>(img + i * M + 4 * ue[c]);
+                    dst[0] = make_float4(y0.x, y0.y, y1.x, y1.y);
+                    dst[1] = make_float4(y2.x, y2.y, y3.x, y3.y);
+                }
+            }
+            // slide, then prefetch the next group's blocks into the freed tail slots
+#pragma unroll
+            for (int i = 0; i < RT; ++i) {
+                wA[c][i] = wA[c][i + GH];
+                wB[c][i] = wB[c][i + GH];
+            }
+#pragma unroll
+            for (int i = 0; i < GH; ++i) {
+                long long g = h + GH + 1 + i;
+                if (g > a.max_block) g = a.max_block;
+                wA[c][RT + i] = ld_iq<FMT>(a.x, g * HB + ue[c]);
+                wB[c][RT + i] = ld_iq<FMT>(a.x, g * HB + ue[c] + Q);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // one quad at a time: interleaving them doubles the live registers
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < GH; ++i) {
+            // opaque copy of the lane index: keeps the per-pass LDS addresses from being hoisted out of the hop loop
+            // (loop-invariant, so the compiler would otherwise park ~100 of them in registers for the whole run)
+            int lane_v = lane;
+            asm volatile("" : "+v"(lane_v));
+            if (h + i < h1) run_fft_passes<CPL>(img + i * M, twl, a, a.out + (size_t)(h + i) * M, lane_v);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 // new_hist[k][j] = block_{H-1-j}[k]
 __global__ void pfb_hist_kernel(const void *x, int fmt, const float2 *old_hist, float2 *new_hist, int M, int T,
                                 long long H) {
@@ -460,6 +723,7 @@ struct wh_pfb {
     int cu_count = 256;
     int gpw_override = 0;       // tuning knob (WH_PFB_GPW)
     int ablate = 0;             // diagnostics (WH_PFB_ABLATE)
+    bool run_ok = false;        // M, T fit pfb_run_kernel
     bool prof = false;          // bracket the fused kernel with events (bench roofline)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
@@ -476,6 +740,13 @@ extern "C" int wh_pfb_create(wh_pfb **out, int M, int T, const double *h_arms) {
     int l2 = 0;
     while ((1 << l2) < M) ++l2;
     p->log2M = ((1 << l2) == M) ? l2 : 0;
+    {
+        int rem = M;
+        while (rem % 2 == 0) rem /= 2;
+        while (rem % 3 == 0) rem /= 3;
+        while (rem % 5 == 0) rem /= 5;
+        p->run_ok = T == RT && M % 4 == 0 && M >= 64 && M <= 512 && M != FM && rem == 1 && !getenv("WH_PFB_NO_RUN");
+    }
     std::vector<float> arms((size_t)M * T);
     for (size_t i = 0; i < arms.size(); ++i) arms[i] = (float)h_arms[i];
     std::vector<float2> tw(M);
@@ -612,7 +883,8 @@ static int pfb_run_fmt(wh_pfb *p, const void *d_iq, int fmt, size_t n, float *d_
     if (!d_iq || !d_out) return set_err(WH_E_ARG, "wh_pfb_run: null buffer");
     int rc;
     const bool fast = (p->M == FM && p->T == FT);
-    long long head = fast ? (H < 8 ? H : 8) : H;
+    const bool run = !fast && p->run_ok;
+    long long head = (fast || run) ? (H < 8 ? H : 8) : H;
     {
         // head hops (need the carried history) + the <= 3 ragged tail hops of the fast path, one launch
         long long tail0 = 0, tailn = 0;
@@ -621,6 +893,56 @@ static int pfb_run_fmt(wh_pfb *p, const void *d_iq, int fmt, size_t n, float *d_
             tailn = H - tail0;
         }
         if ((rc = launch_generic(p, d_iq, fmt, d_out, 0, head, st, tail0, tailn)) != WH_OK) return rc;
+    }
+    if (run && H > 8) {
+        PfbRunArgs a;
+        a.x = d_iq;
+        a.out = reinterpret_cast<float2 *>(d_out);
+        a.arms = p->d_arms;
+        a.tw = p->d_tw;
+        a.M = p->M;
+        int k = 0, rem = p->M / 4;
+        a.radix[k++] = 4;
+        while (rem % 4 == 0) { a.radix[k++] = 4; rem /= 4; }
+        while (rem % 2 == 0) { a.radix[k++] = 2; rem /= 2; }
+        while (rem % 3 == 0) { a.radix[k++] = 3; rem /= 3; }
+        while (rem % 5 == 0) { a.radix[k++] = 5; rem /= 5; }
+        a.n_radix = k;
+        for (int i = 0, s = 1; i < 12; ++i) {
+            if (i >= k) a.radix[i] = 1;
+            a.stride[i] = s;
+            a.inv_stride[i] = 1.0f / (float)s;
+            if (i < k) s *= a.radix[i];
+        }
+        a.first_hop = 8;
+        a.end_hop = H;
+        a.max_block = (long long)(n / (size_t)(p->M / 2)) - 1;
+        constexpr int RGH = 2;
+        // runs of up to 64 hops per wave (halo 12 %), but at least ~24 waves per CU when the input allows
+        long long nh = H - 8;
+        long long hpw = (nh + (long long)p->cu_count * 24 - 1) / ((long long)p->cu_count * 24);
+        if (hpw < 8) hpw = 8;
+        if (hpw > 64) hpw = 64;
+        if (p->gpw_override > 0) hpw = p->gpw_override;
+        hpw = (hpw + RGH - 1) / RGH * RGH;
+        a.hops_per_wave = (int)hpw;
+        const long long waves = (nh + hpw - 1) / hpw;
+        const unsigned nwg = (unsigned)((waves + 3) / 4);
+        const int cpl = p->M <= 256 ? 1 : 2;
+        const size_t smem = ((size_t)p->M + (size_t)cpl * 64 * 18 + (size_t)4 * RGH * p->M) * sizeof(float2);
+        if (p->prof) WH_HIP(hipEventRecord(p->ev0, st));
+        if (cpl == 1) {
+            if (fmt == 1) hipLaunchKernelGGL((pfb_run_kernel<1, 1, RGH>), dim3(nwg), dim3(256), smem, st, a);
+            else hipLaunchKernelGGL((pfb_run_kernel<0, 1, RGH>), dim3(nwg), dim3(256), smem, st, a);
+        } else {
+            if (fmt == 1) hipLaunchKernelGGL((pfb_run_kernel<1, 2, RGH>), dim3(nwg), dim3(256), smem, st, a);
+            else hipLaunchKernelGGL((pfb_run_kernel<0, 2, RGH>), dim3(nwg), dim3(256), smem, st, a);
+        }
+        WH_LAUNCH_CHECK();
+        if (p->prof) {
+            WH_HIP(hipEventRecord(p->ev1, st));
+            p->ev_valid = true;
+        }
     }
     if (fast && H > 8) {
         long long n_groups = (H - 8) / GH;
