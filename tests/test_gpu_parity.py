@@ -834,6 +834,33 @@ def test_a7_pfb_other_channel_counts_vs_oracle(wh, O, fs, bw, M):
     assert np.array_equal(ch.arm_history, ref.arm_history)
 
 
+@pytest.mark.parametrize("fs,bw,M", [(8_000_000, 25_000, 320), (1_600_000, 25_000, 64), (3_200_000, 12_500, 256),
+                                      (6_400_000, 12_500, 512), (3_600_000, 12_500, 288), (2_400_000, 25_000, 96)])
+def test_a7_pfb_run_kernel_equals_per_hop_kernel(wh, fs, bw, M, monkeypatch):
+    """Channel counts 64..512 with 4 | M take the run kernel (one wave per run of hops, register windows, in-place
+    LDS passes); WH_PFB_NO_RUN=1 at construction keeps the one-workgroup-per-hop kernel.  Same pass plan and
+    arithmetic, so the outputs and the carried history must agree bit for bit -- cf32 and int16 input, ragged
+    lengths (partial last run, odd hop counts, fewer hops than the head), three calls in a row."""
+    import torch
+
+    run = wh.PolyphaseChannelizer(fs, bw)
+    monkeypatch.setenv("WH_PFB_NO_RUN", "1")
+    hop = wh.PolyphaseChannelizer(fs, bw)
+    monkeypatch.delenv("WH_PFB_NO_RUN")
+    assert run.channel_count == M == hop.channel_count
+    x = S.noise_c64(M * 700 + 99, 4000 + M, amp=0.25)
+    cuts = [0, M * 3 + 1, M * 3 + 1 + M * 333 + M // 2 + 7, len(x)]       # 5 hops (head only), 665, the rest
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        part = torch.from_numpy(x[lo:hi].copy()).cuda()
+        ya, yb = run.process_device(part).clone(), hop.process_device(part).clone()
+        assert ya.shape == yb.shape and torch.equal(ya, yb), (M, lo, hi)
+    assert np.array_equal(run.arm_history, hop.arm_history)
+    i16 = S.pack_iq16_np(x[: M * 150 + 11])
+    run.reset(); hop.reset()
+    part = torch.from_numpy(i16.copy()).cuda()
+    assert torch.equal(run.process_device(part), hop.process_device(part))
+
+
 def test_operator_from_a_thread_pool(wh, golden):
     """The reference calls _process_channel_dsp_stateless from a ThreadPoolExecutor(max_workers=3)
     (capture.py:1906-1925, 2521-2567): the drop-in must give the same results when 3 threads hammer it with

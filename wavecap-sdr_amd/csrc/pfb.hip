@@ -14,9 +14,12 @@
 //     is exactly what thread t holds -> done in registers; then two radix-16 stages with one wave
 //     per hop (4 hops in flight per workgroup), exchanging through padded LDS images
 //     (conflict-free ds_write_b64 / ds_read_b64 / ds_read_b128).
-// Generic path (any even M): one workgroup per hop, MAC into LDS, then LDS radix-2 FFT (M power of
-// two) or direct DFT (otherwise).  Also used for the first T-1 hops of a call (history) and the
-// tail hops of the fast path.
+// Run path (4 | M, 64 <= M <= 512, T = 9; M = 320 is the reference's benchmark_dsp.py shape): pfb_run_kernel, one
+// wave per run of hops -- the same register-window MAC, first radix-4 pass in registers, remaining Stockham passes
+// in place in the wave's LDS image, last pass straight to HBM (see the comment above the kernel).
+// Generic path (any even M): one workgroup per hop, MAC into LDS, then mixed-radix (4/2/3/5) Stockham passes in LDS,
+// or the direct DFT for a count with another prime factor.  Also used for the first T-1 hops of every call (they
+// read the carried history) and the tail hops of the fast path.
 #include "wh_common.h"
 #include <cmath>
 #include <cstdint>
@@ -522,7 +525,7 @@ __device__ __forceinline__ void run_fft_passes(float2 *img, const float2 *twl, c
 }
 
 template <int FMT, int CPL, int GH>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CPL == 1 ? 1 : 2, CPL == 1 ? 4 : 2))) void pfb_run_kernel(PfbRunArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CPL == 1 ? 4 : 3, CPL == 1 ? 4 : 3))) void pfb_run_kernel(PfbRunArgs a) {
     extern __shared__ __attribute__((aligned(16))) float2 sm[];
     const int M = a.M, Q = M >> 2, HB = M >> 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -545,13 +548,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CPL == 1 ? 
     if (h >= h1) return;
 
     int ue[CPL];            // clamped quad index (idle lanes of a partial round recompute quad Q-1, stores masked)
-    float2 tw1[CPL], tw2[CPL], tw3[CPL];
     float2 wA[CPL][RT + GH], wB[CPL][RT + GH];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
         const int u = lane + 64 * c;
         ue[c] = u < Q ? u : Q - 1;
-        tw1[c] = a.tw[ue[c]]; tw2[c] = a.tw[2 * ue[c]]; tw3[c] = a.tw[3 * ue[c]];
 #pragma unroll
         for (int i = 0; i < RT + GH; ++i) {
             long long g = h - 8 + i;
@@ -579,9 +580,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CPL == 1 ? 
 #define WH_V2(f) (v2f{(f).x, (f).y})
 #pragma unroll
             for (int j = 0; j < RT; ++j) {
-                // two-quad form: taps in two batches (the LDS reads may not cross the asm), or a quad's 36 taps plus
-                // their even-register copies overflow the 3-waves-per-SIMD budget
-                if (CPL > 1 && j == 5) asm volatile("" ::: "memory");
+                // taps in three batches (the LDS reads may not cross the asm), or a quad's 36 taps plus
+                // their even-register copies overflow the occupancy budget (4 waves per SIMD with one quad per lane, 3 with two)
+                if (j == 3 || j == 6) asm volatile("" ::: "memory");
                 const float t0 = tq[j * (CPL * 64)], t1 = tq[(RT + j) * (CPL * 64)];
                 const float t2 = tq[(2 * RT + j) * (CPL * 64)], t3 = tq[(3 * RT + j) * (CPL * 64)];
 #pragma unroll
@@ -598,9 +599,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CPL == 1 ? 
                 float2 y0 = make_float2(y[i][0].x, y[i][0].y), y1 = make_float2(y[i][1].x, y[i][1].y);
                 float2 y2 = make_float2(y[i][2].x, y[i][2].y), y3 = make_float2(y[i][3].x, y[i][3].y);
                 fft4(y0, y1, y2, y3);
-                y1 = cmul(y1, tw1[c]);
-                y2 = cmul(y2, tw2[c]);
-                y3 = cmul(y3, tw3[c]);
+                y1 = cmul(y1, twl[ue[c]]);        // W_M^(u k) from the LDS table (6 registers per quad otherwise)
+                y2 = cmul(y2, twl[2 * ue[c]]);
+                y3 = cmul(y3, twl[3 * ue[c]]);
                 if (lane + 64 * c < Q) {
                     float4 *dst = reinterpret_cast<float4 *>(img + i * M + 4 * ue[c]);
                     dst[0] = make_float4(y0.x, y0.y, y1.x, y1.y);
@@ -847,6 +848,7 @@ static int launch_generic(wh_pfb *p, const void *d_iq, int fmt, float *d_out, lo
     // block size: small channel counts are latency-bound per workgroup (a few hundred points, barriers between
     // passes), so fewer threads per hop and more hops in flight per CU win; WH_PFB_GEN_THREADS overrides
     int bt = p->M <= 512 ? 64 : 256;
+    if (n_hops + n_hops_b <= 2LL * p->cu_count) bt = 256;   // a handful of hops (head of a run-kernel call): latency only
     if (const char *e = getenv("WH_PFB_GEN_THREADS")) { int v = atoi(e); if (v == 64 || v == 128 || v == 256) bt = v; }
     // grid.x is limited to 2^31-1; chunk very long tails (never happens for the fast path)
     const long long MAXG = 1 << 30;
@@ -917,26 +919,26 @@ static int pfb_run_fmt(wh_pfb *p, const void *d_iq, int fmt, size_t n, float *d_
         a.first_hop = 8;
         a.end_hop = H;
         a.max_block = (long long)(n / (size_t)(p->M / 2)) - 1;
-        constexpr int RGH = 2;
+        const int cpl = p->M <= 256 ? 1 : 2;
+        const int rgh = cpl == 1 ? 2 : 1;   // hops per loop iteration (the two-quad form has no registers for a second one)
         // runs of up to 64 hops per wave (halo 12 %), but at least ~24 waves per CU when the input allows
         long long nh = H - 8;
         long long hpw = (nh + (long long)p->cu_count * 24 - 1) / ((long long)p->cu_count * 24);
         if (hpw < 8) hpw = 8;
         if (hpw > 64) hpw = 64;
         if (p->gpw_override > 0) hpw = p->gpw_override;
-        hpw = (hpw + RGH - 1) / RGH * RGH;
+        hpw = (hpw + rgh - 1) / rgh * rgh;
         a.hops_per_wave = (int)hpw;
         const long long waves = (nh + hpw - 1) / hpw;
         const unsigned nwg = (unsigned)((waves + 3) / 4);
-        const int cpl = p->M <= 256 ? 1 : 2;
-        const size_t smem = ((size_t)p->M + (size_t)cpl * 64 * 18 + (size_t)4 * RGH * p->M) * sizeof(float2);
+        const size_t smem = ((size_t)p->M + (size_t)cpl * 64 * 18 + (size_t)4 * rgh * p->M) * sizeof(float2);
         if (p->prof) WH_HIP(hipEventRecord(p->ev0, st));
         if (cpl == 1) {
-            if (fmt == 1) hipLaunchKernelGGL((pfb_run_kernel<1, 1, RGH>), dim3(nwg), dim3(256), smem, st, a);
-            else hipLaunchKernelGGL((pfb_run_kernel<0, 1, RGH>), dim3(nwg), dim3(256), smem, st, a);
+            if (fmt == 1) hipLaunchKernelGGL((pfb_run_kernel<1, 1, 2>), dim3(nwg), dim3(256), smem, st, a);
+            else hipLaunchKernelGGL((pfb_run_kernel<0, 1, 2>), dim3(nwg), dim3(256), smem, st, a);
         } else {
-            if (fmt == 1) hipLaunchKernelGGL((pfb_run_kernel<1, 2, RGH>), dim3(nwg), dim3(256), smem, st, a);
-            else hipLaunchKernelGGL((pfb_run_kernel<0, 2, RGH>), dim3(nwg), dim3(256), smem, st, a);
+            if (fmt == 1) hipLaunchKernelGGL((pfb_run_kernel<1, 2, 1>), dim3(nwg), dim3(256), smem, st, a);
+            else hipLaunchKernelGGL((pfb_run_kernel<0, 2, 1>), dim3(nwg), dim3(256), smem, st, a);
         }
         WH_LAUNCH_CHECK();
         if (p->prof) {
