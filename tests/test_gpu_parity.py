@@ -840,7 +840,7 @@ def test_a7_pfb_run_kernel_equals_per_hop_kernel(wh, fs, bw, M, monkeypatch):
     """Channel counts 64..512 with 4 | M take the run kernel (one wave per run of hops, register windows, in-place
     LDS passes); WH_PFB_NO_RUN=1 at construction keeps the one-workgroup-per-hop kernel.  Same pass plan and
     arithmetic, so the outputs and the carried history must agree bit for bit -- cf32 and int16 input, ragged
-    lengths (partial last run, odd hop counts, fewer hops than the head), three calls in a row."""
+    lengths (partial last run, odd hop counts, fewer hops than the head), four calls in a row."""
     import torch
 
     run = wh.PolyphaseChannelizer(fs, bw)
@@ -849,7 +849,10 @@ def test_a7_pfb_run_kernel_equals_per_hop_kernel(wh, fs, bw, M, monkeypatch):
     monkeypatch.delenv("WH_PFB_NO_RUN")
     assert run.channel_count == M == hop.channel_count
     x = S.noise_c64(M * 700 + 99, 4000 + M, amp=0.25)
-    cuts = [0, M * 3 + 1, M * 3 + 1 + M * 333 + M // 2 + 7, len(x)]       # 5 hops (head only), 665, the rest
+    c1 = M * 3 + 1                      # 5 hops (head only)
+    c2 = c1 + M * 5 + M // 2            # 10 hops (two past the head: one short run)
+    c3 = c2 + M * 333 + M // 2 + 7      # 666 hops, then the rest
+    cuts = [0, c1, c2, c3, len(x)]
     for lo, hi in zip(cuts[:-1], cuts[1:]):
         part = torch.from_numpy(x[lo:hi].copy()).cuda()
         ya, yb = run.process_device(part).clone(), hop.process_device(part).clone()

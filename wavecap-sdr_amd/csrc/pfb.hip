@@ -526,12 +526,15 @@ __device__ __forceinline__ void run_fft_passes(float2 *img, const float2 *twl, c
 
 template <int FMT, int CPL, int GH>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CPL == 1 ? 4 : 3, CPL == 1 ? 4 : 3))) void pfb_run_kernel(PfbRunArgs a) {
+    // three separate LDS objects, so that the compiler knows a twiddle / tap read cannot alias an image write (as
+    // slices of one array every twiddle read of a pass waited for the preceding image write: three exposed LDS round
+    // trips per butterfly)
+    __shared__ float2 twl[512];                                 // [M]
+    __shared__ float tapl[36 * CPL * 64];                       // [36][CPL*64]
     extern __shared__ __attribute__((aligned(16))) float2 sm[];
     const int M = a.M, Q = M >> 2, HB = M >> 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float2 *twl = sm;                                           // [M]
-    float *tapl = reinterpret_cast<float *>(sm + M);            // [36][CPL*64]
-    float2 *img = sm + M + CPL * 64 * 18 + wave * GH * M;       // GH images of M per wave
+    float2 *img = sm + wave * GH * M;                           // GH images of M per wave
 
     for (int i = threadIdx.x; i < M; i += 256) twl[i] = a.tw[i];
     for (int i = threadIdx.x; i < 36 * CPL * 64; i += 256) {
@@ -931,7 +934,7 @@ static int pfb_run_fmt(wh_pfb *p, const void *d_iq, int fmt, size_t n, float *d_
         a.hops_per_wave = (int)hpw;
         const long long waves = (nh + hpw - 1) / hpw;
         const unsigned nwg = (unsigned)((waves + 3) / 4);
-        const size_t smem = ((size_t)p->M + (size_t)cpl * 64 * 18 + (size_t)4 * rgh * p->M) * sizeof(float2);
+        const size_t smem = (size_t)4 * rgh * p->M * sizeof(float2);   // images; twiddles and taps are static LDS
         if (p->prof) WH_HIP(hipEventRecord(p->ev0, st));
         if (cpl == 1) {
             if (fmt == 1) hipLaunchKernelGGL((pfb_run_kernel<1, 1, 2>), dim3(nwg), dim3(256), smem, st, a);
