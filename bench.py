@@ -394,6 +394,22 @@ def main() -> None:
             torch.cuda.synchronize()
             line["roofline"]["device_copy_yardstick_GBps"] = round(3 * 4 * (1 << 28) * 10 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9, 1)
             del src, dst
+            # the filterbank's own traffic shape with no arithmetic (hand-written: 16-byte loads, two 16-byte store
+            # streams, one pass per workgroup): 2^28 samples in, 2 x 2^28 out -- what the memory system gives this
+            # read:write mix when nothing else is in the way
+            from wavehip import _lib as _wl
+            ys = torch.empty(2 * n + 4096, dtype=torch.complex64, device="cuda")
+            for _ in range(3):
+                _wl.check(_wl.lib.wh_diag_stream_1r2w(x.data_ptr(), ys.data_ptr(), n, _wl.stream_ptr(torch)), "diag")
+            ev0.record()
+            for _ in range(10):
+                _wl.check(_wl.lib.wh_diag_stream_1r2w(x.data_ptr(), ys.data_ptr(), n, _wl.stream_ptr(torch)), "diag")
+            ev1.record()
+            torch.cuda.synchronize()
+            sy = 24.0 * n * 10 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
+            line["roofline"]["stream_1r2w_yardstick_GBps"] = round(sy, 1)
+            line["roofline"]["frac_of_stream_yardstick"] = round(line["roofline"]["achieved"] / sy, 4)
+            del ys
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline()
         if world == 1 and not args.no_secondary:

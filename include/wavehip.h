@@ -176,6 +176,11 @@ int wh_pfb_extract_channel(const float *d_out, size_t hops, int channel_count, i
 int wh_pfb_channel_stats(wh_pfb *p, const float *d_out, size_t hops, double *d_stats, int accumulate,
                          void *stream);
 
+/* Diagnostics (no reference counterpart): the filterbank's HBM traffic shape with no arithmetic -- reads n complex64
+ * from d_in, writes them twice (2n complex64) to d_out; n even.  bench.py times it beside the filterbank as the
+ * in-process yardstick for a 1 : 2 read : write stream. */
+int wh_diag_stream_1r2w(const float *d_in, float *d_out, size_t n, void *stream);
+
 /* ---- A8: spectrum, dsp/fft/scipy_backend.py:38-79 ScipyFFTBackend.execute ---------
  * d_iq: complex64, frame f starts at d_iq + f*frame_stride (complex units); uses the
  * first fft_size samples; d_power_db float32[n_frames][fft_size], fft-shifted,
