@@ -864,6 +864,21 @@ def test_a7_pfb_run_kernel_equals_per_hop_kernel(wh, fs, bw, M, monkeypatch):
     assert torch.equal(run.process_device(part), hop.process_device(part))
 
 
+def test_diag_stream_yardstick_copies_twice(wh):
+    """wh_diag_stream_1r2w (the no-arithmetic traffic yardstick bench.py times beside the filterbank) really moves the
+    bytes it is credited with: the input appears twice in the output, ragged length included; odd n is refused."""
+    import torch
+    from wavehip import _lib
+
+    for n in (2, 1000, 4096 * 3 + 6, 1 << 20):
+        x = torch.view_as_complex(torch.randn(n, 2, device="cuda"))
+        y = torch.zeros(2 * n, dtype=torch.complex64, device="cuda")
+        _lib.check(_lib.lib.wh_diag_stream_1r2w(x.data_ptr(), y.data_ptr(), n, _lib.stream_ptr(torch)), "diag")
+        torch.cuda.synchronize()
+        assert torch.equal(y[:n], x) and torch.equal(y[n:], x)
+    assert _lib.lib.wh_diag_stream_1r2w(x.data_ptr(), y.data_ptr(), 3, None) != 0
+
+
 def test_operator_from_a_thread_pool(wh, golden):
     """The reference calls _process_channel_dsp_stateless from a ThreadPoolExecutor(max_workers=3)
     (capture.py:1906-1925, 2521-2567): the drop-in must give the same results when 3 threads hammer it with

@@ -548,18 +548,25 @@ __device__ __forceinline__ void iir_stage(float (*tile)[65], int cnt, int lane, 
 //             written: the true state differs by < 1e-10 relative), pass B runs it over its segment in place.  64x less
 //             sequential depth for (seg + warm) / seg times the arithmetic.  Not available with the AGC (its release
 //             time constant spans the chunk).
+//             With few rows the launch is pure latency and most CUs idle, so the row may be cut finer: blockDim.x / 64
+//             waves per row, 64 segments each (the host picks the wave count from the bank's channel count only, so a
+//             bank's numbers do not depend on how many chunks a call carries).
+constexpr int ROWS_MAXW = 8;
 template <int NS>
-__global__ __launch_bounds__(64) void chan_rows_kernel(float *rows, double *acc, int n_rows, int N, StageArr sa,
-                                                      AgcDev agc, int seg, int warm) {
-    __shared__ float tile[ROWS_CH][65];   // [sample][row], padded: column walks and row walks are both conflict-free
-    __shared__ StageDev st_s[NS > 0 ? NS : 1];
-    const int lane = threadIdx.x;
-    for (int i = lane; i < NS * (int)(sizeof(StageDev) / 4); i += 64)
+__global__ __launch_bounds__(64 * ROWS_MAXW) void chan_rows_kernel(float *rows, double *acc, int n_rows, int N, StageArr sa,
+                                                                  AgcDev agc, int seg, int warm) {
+    extern __shared__ __attribute__((aligned(16))) float tile_raw[];   // per wave [ROWS_CH][65]: [sample][row], padded:
+    __shared__ StageDev st_s[NS > 0 ? NS : 1];                         // column walks and row walks are conflict-free
+    __shared__ double red_s[ROWS_MAXW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float (*tile)[65] = reinterpret_cast<float (*)[65]>(tile_raw + (size_t)wave * ROWS_CH * 65);
+    for (int i = threadIdx.x; i < NS * (int)(sizeof(StageDev) / 4); i += blockDim.x)
         reinterpret_cast<int *>(st_s)[i] = reinterpret_cast<const int *>(sa.st)[i];
     __syncthreads();
     const int r0 = seg ? blockIdx.x : blockIdx.x * 64;
-    int nr = seg ? (N + seg - 1) / seg : n_rows - r0;   // live lanes (virtual rows)
-    if (nr > 64) nr = 64;
+    const int s0 = wave * 64;                                  // first segment of this wave (time-parallel mode)
+    int nr = seg ? (N + seg - 1) / seg - s0 : n_rows - r0;     // live lanes (virtual rows)
+    nr = nr < 0 ? 0 : (nr > 64 ? 64 : nr);
     double z[NS > 0 ? NS : 1][MAX_ORD - 1];
 #pragma unroll
     for (int s = 0; s < NS; ++s)
@@ -572,12 +579,12 @@ __global__ __launch_bounds__(64) void chan_rows_kernel(float *rows, double *acc,
         // virtual row l: offset vo(l) into the buffer, length vn(l)
         auto vo = [&](int l) -> size_t {
             if (!seg) return (size_t)(r0 + l) * N;
-            const int st = l * seg;
+            const int st = (s0 + l) * seg;
             return (size_t)r0 * N + (pass == 0 ? st - (st < warm ? st : warm) : st);
         };
         auto vn = [&](int l) -> int {
             if (!seg) return N;
-            const int st = l * seg;
+            const int st = (s0 + l) * seg;
             if (pass == 0) return st < warm ? st : warm;
             const int left = N - st;
             return left < seg ? (left > 0 ? left : 0) : seg;
@@ -639,7 +646,13 @@ __global__ __launch_bounds__(64) void chan_rows_kernel(float *rows, double *acc,
     }
     if (seg) {
         for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
-        if (lane == 0) acc[(size_t)r0 * 2 + 1] = ss;
+        if (lane == 0) red_s[wave] = ss;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red_s[w];
+            acc[(size_t)r0 * 2 + 1] = t;
+        }
     } else if (lane < nr) {
         acc[(size_t)(r0 + lane) * 2 + 1] = ss;
     }
@@ -1447,10 +1460,16 @@ extern "C" int wh_chanbank_run(wh_chanbank *b, const void *d_in, size_t n_chunks
             g.att_b0 = c.agc_att_b0; g.att_a1 = c.agc_att_a1;
             g.rel_b0 = c.agc_rel_b0; g.rel_a1 = c.agc_rel_a1;
             // time-parallel mode when it at least halves the sequential depth (see chan_rows_kernel)
-            int seg = 0;
+            int seg = 0, rw = 1;
             if (!c.agc && c.iir_warmup > 0 && c.n_stages > 0) {
                 const int sg = (c.chunk_len + 63) / 64;
-                if (sg + c.iir_warmup <= c.chunk_len / 2) seg = sg;
+                if (sg + c.iir_warmup <= c.chunk_len / 2) {
+                    // waves per row: a property of the bank (channel count, chunk length), never of the call
+                    rw = c.n_channels <= 16 ? ROWS_MAXW : c.n_channels <= 64 ? 4 : 1;
+                    while (rw > 1 && c.chunk_len < 64 * rw * 16) rw >>= 1;
+                    if (const char *e = getenv("WH_ROWS_WAVES")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) rw = v; }
+                    seg = (c.chunk_len + 64 * rw - 1) / (64 * rw);
+                }
             }
             const bool force_seq = getenv("WH_IIR_SEQ") != nullptr;   // diagnostics: force the sequential form
             if (force_seq) seg = 0;
@@ -1460,7 +1479,15 @@ extern "C" int wh_chanbank_run(wh_chanbank *b, const void *d_in, size_t n_chunks
                 WH_LAUNCH_CHECK();
             } else {
             const dim3 rg(seg ? (unsigned)rows : (unsigned)((rows + 63) / 64));
-#define WH_ROWS(NS_) hipLaunchKernelGGL(chan_rows_kernel<NS_>, rg, dim3(64), 0, st, a.fm_out, b->d_acc, (int)rows, c.chunk_len, b->stages, g, seg, c.iir_warmup)
+            const size_t tile_bytes = (size_t)rw * ROWS_CH * 65 * sizeof(float);
+#define WH_ROWS(NS_)                                                                                                      \
+    do {                                                                                                                  \
+        if (tile_bytes > 64 * 1024)                                                                                       \
+            WH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chan_rows_kernel<NS_>),                             \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_bytes));                     \
+        hipLaunchKernelGGL(chan_rows_kernel<NS_>, rg, dim3(64 * rw), tile_bytes, st, a.fm_out, b->d_acc, (int)rows,       \
+                           c.chunk_len, b->stages, g, seg, c.iir_warmup);                                                 \
+    } while (0)
             switch (c.n_stages) {
                 case 0: WH_ROWS(0); break;
                 case 1: WH_ROWS(1); break;
