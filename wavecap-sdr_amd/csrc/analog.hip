@@ -491,49 +491,65 @@ struct StageArr {
 // stage's dtype; the next sample is fetched from LDS while the current one walks the recurrence.
 constexpr int ROWS_CH = 64;
 
-template <int NC, bool F64>
+template <int NC, bool F64, bool UNI = false>
 __device__ __forceinline__ void iir_run(float (*tile)[65], int cnt, int lane, double (&z)[MAX_ORD - 1], const StageDev &S) {
     // S lives in LDS: the coefficients arrive in VGPRs (read from the scalar kernarg copy the compiler keeps them in
     // SGPRs, runs out of those and round-trips them through v_readlane inside the sample loop)
     double b[NC], a[NC];
 #pragma unroll
     for (int k = 0; k < NC; ++k) { b[k] = S.b[k]; a[k] = S.a[k]; }
-    float xn = tile[0][lane];
-    for (int j = 0; j < cnt; ++j) {
-        const float x = xn;
-        if (j + 1 < cnt) xn = tile[j + 1][lane];
+    auto step = [&](float x) -> float {
         if (F64) {
             const double xd = (double)x;
             const double y = __dadd_rn(z[0], __dmul_rn(b[0], xd));
 #pragma unroll
             for (int k = 0; k < NC - 2; ++k) z[k] = __dsub_rn(__dadd_rn(z[k + 1], __dmul_rn(xd, b[k + 1])), __dmul_rn(y, a[k + 1]));
             if (NC >= 2) z[NC - 2] = __dsub_rn(__dmul_rn(xd, b[NC - 1]), __dmul_rn(y, a[NC - 1]));
-            tile[j][lane] = (float)y;
+            return (float)y;
         } else {
             const float y = __fadd_rn((float)z[0], __fmul_rn((float)b[0], x));
 #pragma unroll
             for (int k = 0; k < NC - 2; ++k)
                 z[k] = (double)__fsub_rn(__fadd_rn((float)z[k + 1], __fmul_rn(x, (float)b[k + 1])), __fmul_rn(y, (float)a[k + 1]));
             if (NC >= 2) z[NC - 2] = (double)__fsub_rn(__fmul_rn(x, (float)b[NC - 1]), __fmul_rn(y, (float)a[NC - 1]));
-            tile[j][lane] = y;
+            return y;
         }
+    };
+    if (UNI) {
+        // cnt is the same in every lane (the caller pads short rows with zeros where that is exact): a scalar trip
+        // count and a branch-free prefetch -- no exec masking or divergent branches in the sample loop
+        cnt = __builtin_amdgcn_readfirstlane(cnt);
+        float xn = tile[0][lane];
+        for (int j = 0; j < cnt; ++j) {
+            const float x = xn;
+            const int jn = j + 1 < cnt ? j + 1 : j;   // scalar
+            xn = tile[jn][lane];
+            tile[j][lane] = step(x);
+        }
+        return;
+    }
+    float xn = tile[0][lane];
+    for (int j = 0; j < cnt; ++j) {
+        const float x = xn;
+        if (j + 1 < cnt) xn = tile[j + 1][lane];
+        tile[j][lane] = step(x);
     }
 }
 
-template <bool F64>
+template <bool F64, bool UNI = false>
 __device__ __forceinline__ void iir_stage(float (*tile)[65], int cnt, int lane, double (&z)[MAX_ORD - 1], const StageDev &S) {
     switch (__builtin_amdgcn_readfirstlane(S.n)) {   // wave-uniform, once per (tile, stage)
-        case 1: iir_run<1, F64>(tile, cnt, lane, z, S); break;
-        case 2: iir_run<2, F64>(tile, cnt, lane, z, S); break;
-        case 3: iir_run<3, F64>(tile, cnt, lane, z, S); break;
-        case 4: iir_run<4, F64>(tile, cnt, lane, z, S); break;
-        case 5: iir_run<5, F64>(tile, cnt, lane, z, S); break;
-        case 6: iir_run<6, F64>(tile, cnt, lane, z, S); break;
-        case 7: iir_run<7, F64>(tile, cnt, lane, z, S); break;
-        case 8: iir_run<8, F64>(tile, cnt, lane, z, S); break;
-        case 9: iir_run<9, F64>(tile, cnt, lane, z, S); break;
-        case 10: iir_run<10, F64>(tile, cnt, lane, z, S); break;
-        default: iir_run<11, F64>(tile, cnt, lane, z, S); break;
+        case 1: iir_run<1, F64, UNI>(tile, cnt, lane, z, S); break;
+        case 2: iir_run<2, F64, UNI>(tile, cnt, lane, z, S); break;
+        case 3: iir_run<3, F64, UNI>(tile, cnt, lane, z, S); break;
+        case 4: iir_run<4, F64, UNI>(tile, cnt, lane, z, S); break;
+        case 5: iir_run<5, F64, UNI>(tile, cnt, lane, z, S); break;
+        case 6: iir_run<6, F64, UNI>(tile, cnt, lane, z, S); break;
+        case 7: iir_run<7, F64, UNI>(tile, cnt, lane, z, S); break;
+        case 8: iir_run<8, F64, UNI>(tile, cnt, lane, z, S); break;
+        case 9: iir_run<9, F64, UNI>(tile, cnt, lane, z, S); break;
+        case 10: iir_run<10, F64, UNI>(tile, cnt, lane, z, S); break;
+        default: iir_run<11, F64, UNI>(tile, cnt, lane, z, S); break;
     }
 }
 
@@ -553,7 +569,7 @@ __device__ __forceinline__ void iir_stage(float (*tile)[65], int cnt, int lane, 
 //             bank's numbers do not depend on how many chunks a call carries).
 constexpr int ROWS_MAXW = 8;
 template <int NS>
-__global__ __launch_bounds__(64 * ROWS_MAXW) void chan_rows_kernel(float *rows, double *acc, int n_rows, int N, StageArr sa,
+__global__ __launch_bounds__(NS <= 3 ? 64 * ROWS_MAXW : 64) void chan_rows_kernel(float *rows, double *acc, int n_rows, int N, StageArr sa,
                                                                   AgcDev agc, int seg, int warm) {
     extern __shared__ __attribute__((aligned(16))) float tile_raw[];   // per wave [ROWS_CH][65]: [sample][row], padded:
     __shared__ StageDev st_s[NS > 0 ? NS : 1];                         // column walks and row walks are conflict-free
@@ -577,16 +593,24 @@ __global__ __launch_bounds__(64 * ROWS_MAXW) void chan_rows_kernel(float *rows, 
     double ss = 0.0;
     for (int pass = seg ? 0 : 1; pass < 2; ++pass) {
         // virtual row l: offset vo(l) into the buffer, length vn(l)
-        auto vo = [&](int l) -> size_t {
-            if (!seg) return (size_t)(r0 + l) * N;
+        // Every lane walks the same number of samples per tile (a scalar trip count in iir_run): the warm-up pass is
+        // RIGHT-aligned -- virtual sample i of segment l is chunk sample st - warm + i, zero where that is before the
+        // row (zero input on zero state leaves the state exactly zero) -- and a short last segment is followed by
+        // zeros whose outputs are never written.
+        auto vo = [&](int l) -> long long {
+            if (!seg) return (long long)(r0 + l) * N;
             const int st = (s0 + l) * seg;
-            return (size_t)r0 * N + (pass == 0 ? st - (st < warm ? st : warm) : st);
+            return (long long)r0 * N + (pass == 0 ? st - warm : st);
         };
-        auto vn = [&](int l) -> int {
-            if (!seg) return N;
+        auto vlo = [&](int l) -> int {   // first virtual index that exists
+            if (!seg || pass == 1) return 0;
             const int st = (s0 + l) * seg;
-            if (pass == 0) return st < warm ? st : warm;
-            const int left = N - st;
+            return st < warm ? warm - st : 0;
+        };
+        auto vn = [&](int l) -> int {    // one past the last virtual index that exists
+            if (!seg) return N;
+            if (pass == 0) return warm;
+            const int left = N - (s0 + l) * seg;
             return left < seg ? (left > 0 ? left : 0) : seg;
         };
         const int span = seg ? (pass == 0 ? warm : seg) : N;
@@ -597,20 +621,21 @@ __global__ __launch_bounds__(64 * ROWS_MAXW) void chan_rows_kernel(float *rows, 
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
                     const int l = l0 + u;
-                    v[u] = (l < nr && lane < vn(l) - i0) ? rows[vo(l) + i0 + lane] : 0.0f;
+                    const int i = i0 + lane;
+                    v[u] = (l < nr && i < vn(l) && i >= vlo(l)) ? rows[vo(l) + i] : 0.0f;
                 }
 #pragma unroll
-                for (int u = 0; u < 16; ++u)
-                    if (l0 + u < nr) tile[lane][l0 + u] = v[u];
+                for (int u = 0; u < 16; ++u) tile[lane][l0 + u] = v[u];   // columns nr.. of the last group: zeros
             }
             __syncthreads();
-            int cnt = my_n - i0;
+            int cnt = my_n - i0;                       // this lane's live samples in the tile (metrics, AGC)
             if (cnt > ROWS_CH) cnt = ROWS_CH;
-            if (cnt > 0) {
+            const int cntu = span - i0 < ROWS_CH ? span - i0 : ROWS_CH;   // wave-uniform walk
+            {
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
-                    if (sa.st[s].is_f64) iir_stage<true>(tile, cnt, lane, z[s], st_s[s]);
-                    else iir_stage<false>(tile, cnt, lane, z[s], st_s[s]);
+                    if (sa.st[s].is_f64) iir_stage<true, true>(tile, cntu, lane, z[s], st_s[s]);
+                    else iir_stage<false, true>(tile, cntu, lane, z[s], st_s[s]);
                 }
                 if (agc.on) {
                     for (int j = 0; j < cnt; ++j) {
@@ -1465,9 +1490,10 @@ extern "C" int wh_chanbank_run(wh_chanbank *b, const void *d_in, size_t n_chunks
                 const int sg = (c.chunk_len + 63) / 64;
                 if (sg + c.iir_warmup <= c.chunk_len / 2) {
                     // waves per row: a property of the bank (channel count, chunk length), never of the call
-                    rw = c.n_channels <= 16 ? ROWS_MAXW : c.n_channels <= 64 ? 4 : 1;
+                    // (chains of more than 3 stages keep one wave per row: their state alone is 20 VGPRs per stage)
+                    rw = c.n_stages > 3 ? 1 : c.n_channels <= 16 ? ROWS_MAXW : c.n_channels <= 64 ? 4 : 1;
                     while (rw > 1 && c.chunk_len < 64 * rw * 16) rw >>= 1;
-                    if (const char *e = getenv("WH_ROWS_WAVES")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) rw = v; }
+                    if (const char *e = getenv("WH_ROWS_WAVES")) { int v = atoi(e); if (c.n_stages <= 3 && (v == 1 || v == 2 || v == 4 || v == 8)) rw = v; }
                     seg = (c.chunk_len + 64 * rw - 1) / (64 * rw);
                 }
             }
