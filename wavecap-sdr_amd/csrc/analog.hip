@@ -616,16 +616,17 @@ __global__ __launch_bounds__(NS <= 3 ? 64 * ROWS_MAXW : 64) void chan_rows_kerne
         const int span = seg ? (pass == 0 ? warm : seg) : N;
         const int my_n = lane < nr ? vn(lane) : 0;
         for (int i0 = 0; i0 < span; i0 += ROWS_CH) {
-            for (int l0 = 0; l0 < nr; l0 += 16) {   // 16 independent loads in flight before the first LDS write
-                float v[16];
+            constexpr int LG = NS <= 3 ? 32 : 16;   // loads in flight before the first LDS write: the whole tile when
+            for (int l0 = 0; l0 < nr; l0 += LG) {   // the stage states leave room (one exposed memory latency per tile)
+                float v[LG];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
+                for (int u = 0; u < LG; ++u) {
                     const int l = l0 + u;
                     const int i = i0 + lane;
                     v[u] = (l < nr && i < vn(l) && i >= vlo(l)) ? rows[vo(l) + i] : 0.0f;
                 }
 #pragma unroll
-                for (int u = 0; u < 16; ++u) tile[lane][l0 + u] = v[u];   // columns nr.. of the last group: zeros
+                for (int u = 0; u < LG; ++u) tile[lane][l0 + u] = v[u];   // columns nr.. of the last group: zeros
             }
             __syncthreads();
             int cnt = my_n - i0;                       // this lane's live samples in the tile (metrics, AGC)
