@@ -881,6 +881,27 @@ def test_a7_pfb_other_tap_counts_vs_oracle(wh, O, fs, bw, M, T):
     assert np.array_equal(ch.arm_history, ref.arm_history)
 
 
+def test_a7_pfb_prefetch_forms_agree(wh, monkeypatch):
+    """The fused 1024-channel kernel prefetches the next group's samples either into registers (complex64 default) or
+    through the LDS DMA with counted waits (int16 default); WH_PFB_VARIANT = 1 / 3 forces one form for both formats.
+    Same arithmetic, so all four (format, form) pairs agree bit for bit, ragged tail and second call included."""
+    import torch
+
+    x = S.noise_c64(1024 * 260 + 333, 77, amp=0.25)
+    i16 = torch.from_numpy(S.pack_iq16_np(x)).cuda()
+    xq = torch.from_numpy(wh.unpack_iq16(S.pack_iq16_np(x))).cuda()
+    outs = {}
+    for v in ("1", "3"):
+        monkeypatch.setenv("WH_PFB_VARIANT", v)
+        a, b = wh.PolyphaseChannelizer(10_000_000, 9765), wh.PolyphaseChannelizer(10_000_000, 9765)
+        cut = 1024 * 150 + 512
+        outs[v] = [torch.cat([a.process_device(xq[:cut]), a.process_device(xq[cut:])]),
+                   torch.cat([b.process_device(i16[:2 * cut]), b.process_device(i16[2 * cut:])])]
+    monkeypatch.delenv("WH_PFB_VARIANT")
+    ref = outs["1"][0]
+    assert all(torch.equal(ref, o) for v in outs for o in outs[v])
+
+
 def test_diag_stream_yardstick_copies_twice(wh):
     """wh_diag_stream_1r2w (the no-arithmetic traffic yardstick bench.py times beside the filterbank) really moves the
     bytes it is credited with: the input appears twice in the output, ragged length included; odd n is refused."""

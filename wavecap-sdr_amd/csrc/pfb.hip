@@ -64,10 +64,17 @@ struct PfbFastArgs {
     int ablate;             // diagnostics only (WH_PFB_ABLATE): 1 = suppress stores
 };
 
-template <int FMT>
+// GLDS: the next group's samples are prefetched into LDS by the DMA path (global_load_lds, inline asm: no register
+// results, so nothing the register allocator could copy early) and waited for with a COUNTED s_waitcnt: completion is
+// reported in issue order (tools/ubench/vmcnt_order.hip), so vmcnt(8) -- the eight output stores issued after the
+// prefetch -- retires the prefetch and leaves the stores in flight.  With ordinary loads hipcc's wait for the
+// prefetched registers is vmcnt(0): every group drained its predecessor's stores before its arm MAC could finish.
+template <int FMT, bool GLDS = false>
 __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
-    __shared__ __attribute__((aligned(16))) float2 lds[GH * LDS_HOP + 256];
+    constexpr int PRE_BYTES = GLDS ? GH * FHOP * (FMT == 1 ? 4 : 8) : 0;   // GH half-blocks of samples
+    __shared__ __attribute__((aligned(16))) float2 lds[GH * LDS_HOP + 256 + PRE_BYTES / 8];
     float2 *tw256 = lds + GH * LDS_HOP;
+    unsigned char *pre = reinterpret_cast<unsigned char *>(lds + GH * LDS_HOP + 256);
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -113,6 +120,8 @@ __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
         wB[i] = ld_iq<FMT>(a.x, xp + i * FHOP + 256);
     }
 
+    if (GLDS) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the window fill is complete before the loop, so that no
+                                                    // wait for it is placed inside the loop (it would drain the stores)
     for (long long g = g0; g < g1; ++g, h += GH) {
         // ---- arm MAC + radix-4 stage for GH hops --------------------------------------------
 #pragma unroll
@@ -149,11 +158,30 @@ __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
             wB[i] = wB[i + GH];
         }
         if (g + 1 < g1) {   // (a second prefetch stage, one more group ahead, measured 1 % slower)
-            const long long xn = (h + GH + 1) * FHOP + t;
+            if (GLDS) {
+                // GH half-blocks, contiguous in memory, copied linearly: 16 bytes per lane, lane-linear in LDS
+                constexpr int NJ = PRE_BYTES / 16 / 256;
+                const unsigned char *src = reinterpret_cast<const unsigned char *>(a.x) +
+                                           (size_t)(h + GH + 1) * FHOP * (FMT == 1 ? 4 : 8);
 #pragma unroll
-            for (int i = 0; i < GH; ++i) {
-                wA[9 + i] = ld_iq<FMT>(a.x, xn + i * FHOP);
-                wB[9 + i] = ld_iq<FMT>(a.x, xn + i * FHOP + 256);
+                for (int j = 0; j < NJ; ++j) {
+                    const unsigned char *gp = src + (size_t)(j * 256 + t) * 16;
+                    unsigned base = (unsigned)(uintptr_t)pre + (unsigned)(j * 256 + wave * 64) * 16;
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    unsigned save;
+                    asm volatile("s_mov_b32 %0, m0\n\t"
+                                 "s_mov_b32 m0, %1\n\t"
+                                 "global_load_lds_dwordx4 %2, off\n\t"
+                                 "s_mov_b32 m0, %0"
+                                 : "=&s"(save) : "s"(base), "v"(gp) : "memory");
+                }
+            } else {
+                const long long xn = (h + GH + 1) * FHOP + t;
+#pragma unroll
+                for (int i = 0; i < GH; ++i) {
+                    wA[9 + i] = ld_iq<FMT>(a.x, xn + i * FHOP);
+                    wB[9 + i] = ld_iq<FMT>(a.x, xn + i * FHOP + 256);
+                }
             }
         }
         __syncthreads();
@@ -232,7 +260,28 @@ __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
                 }
             }
         }
+        if (GLDS) {
+            // the prefetch is older than this group's 8 stores: retire it, keep them in flight (no stores in the
+            // diagnostic no-store mode: then wait for everything)
+            if (a.ablate) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        }
         __syncthreads();
+        if (GLDS && g + 1 < g1) {
+#pragma unroll
+            for (int i = 0; i < GH; ++i) {
+                if (FMT == 1) {
+                    const short2 *p16 = reinterpret_cast<const short2 *>(pre);
+                    const short2 va = p16[i * FHOP + t], vb = p16[i * FHOP + t + 256];
+                    wA[9 + i] = make_float2((float)va.x * (1.0f / 32768.0f), (float)va.y * (1.0f / 32768.0f));
+                    wB[9 + i] = make_float2((float)vb.x * (1.0f / 32768.0f), (float)vb.y * (1.0f / 32768.0f));
+                } else {
+                    const float2 *p32 = reinterpret_cast<const float2 *>(pre);
+                    wA[9 + i] = p32[i * FHOP + t];
+                    wB[9 + i] = p32[i * FHOP + t + 256];
+                }
+            }
+        }
     }
 }
 
@@ -734,6 +783,7 @@ struct wh_pfb {
     int cu_count = 256;
     int gpw_override = 0;       // tuning knob (WH_PFB_GPW)
     int ablate = 0;             // diagnostics (WH_PFB_ABLATE)
+    int variant = 0;            // WH_PFB_VARIANT (diagnostics): 1 = register prefetch, 3 = LDS-DMA prefetch, for both formats
     bool run_ok = false;        // M, T fit pfb_run_kernel
     bool prof = false;          // bracket the fused kernel with events (bench roofline)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -748,6 +798,7 @@ extern "C" int wh_pfb_create(wh_pfb **out, int M, int T, const double *h_arms) {
     p->M = M; p->T = T;
     if (const char *e = getenv("WH_PFB_GPW")) p->gpw_override = atoi(e);
     if (const char *e = getenv("WH_PFB_ABLATE")) p->ablate = atoi(e);
+    if (const char *e = getenv("WH_PFB_VARIANT")) p->variant = atoi(e);
     int l2 = 0;
     while ((1 << l2) < M) ++l2;
     p->log2M = ((1 << l2) == M) ? l2 : 0;
@@ -981,7 +1032,14 @@ static int pfb_run_fmt(wh_pfb *p, const void *d_iq, int fmt, size_t n, float *d_
             a.n_wg = (int)nwg;
             a.ablate = p->ablate;
             if (p->prof) WH_HIP(hipEventRecord(p->ev0, st));
-            if (fmt == 1)
+            // prefetch path: int16 input through the LDS DMA (16 bytes per lane instead of 4: 1.30 -> 1.15 ms per 2^28
+            // samples), complex64 input through registers (the DMA detour costs it 4 %); WH_PFB_VARIANT = 1 / 3 forces
+            // the register / DMA form for both
+            const bool dma = p->variant == 3 || (p->variant != 1 && fmt == 1);
+            if (dma) {
+                if (fmt == 1) hipLaunchKernelGGL((pfb1024_kernel<1, true>), dim3((unsigned)nwg), dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((pfb1024_kernel<0, true>), dim3((unsigned)nwg), dim3(256), 0, st, a);
+            } else if (fmt == 1)
                 hipLaunchKernelGGL(pfb1024_kernel<1>, dim3((unsigned)nwg), dim3(256), 0, st, a);
             else
                 hipLaunchKernelGGL(pfb1024_kernel<0>, dim3((unsigned)nwg), dim3(256), 0, st, a);
