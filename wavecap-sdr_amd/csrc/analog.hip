@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void fmbank_fused_kernel(FmArgs a) {
         __syncthreads();  // window (and, first time, taps) visible
 
         // phase 2: y[m0+o] = sum_i fm_s[o*down + i] * trev[i].
-        if (a.TO == 128 && (a.down & 1) == 0) {
+        if (a.TO > 96 && a.TO <= 128 && (a.TO & 3) == 0 && (a.down & 1) == 0) {
             // 8 lanes share 4 outputs: each lane takes a contiguous 1/8 of the (paired) taps for all 4, so a tap pair
             // is read once per 8 MACs; packed FMAs; float32 partial sums over 32 pairs, added in float64 (error ~3e-7
             // of the output scale; scipy accumulates in float64).
@@ -291,6 +291,7 @@ __global__ __launch_bounds__(256) void fmbank_fused_kernel(FmArgs a) {
             const v2f *f0 = reinterpret_cast<const v2f *>(fm_s + (4 * og) * a.down);
             const int dstep = a.down >> 1;   // output stride in pairs
             double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+            if (4 * og >= a.TO) p_hi = p_lo;   // tiles of 100..124 outputs: the last groups have nothing to do
             for (int pb = p_lo; pb < p_hi; pb += 32) {
                 int pe = pb + 32 < p_hi ? pb + 32 : p_hi;
                 v2f s0 = {0.f, 0.f}, s1 = {0.f, 0.f}, s2 = {0.f, 0.f}, s3 = {0.f, 0.f};
@@ -1378,10 +1379,24 @@ extern "C" int wh_chanbank_create(wh_chanbank **out, const wh_chanbank_cfg *c) {
         c->ntaps <= FM_MAX_TAPS) {
         int TO = 256;
         while (TO > 8 && c->ntaps + (TO - 1) * c->down > FM_MAX_SPAN) TO >>= 1;
+        // the kernel's 86 VGPRs allow 5 workgroups per CU, LDS only 4 at 128 outputs per tile with the reference's
+        // 1001 taps at 50:1 (33.4 KB): a few outputs fewer per tile fit 5, and the launch is occupancy-sensitive (2 / 3 /
+        // 4 workgroups per CU: 4.07 / 2.96 / 2.48 ms).  Measured: 124 outputs (32.6 KB) still runs 4 per CU, 120
+        // (31.8 KB) runs 5: 2.48 -> 2.35 ms; 116 / 112 give the gain back to emptier tiles.
+        if (TO == 128 && (c->down & 1) == 0 && !getenv("WH_FM_TO128")) {
+            auto bytes = [&](int to) {
+                return (size_t)((c->ntaps + 1) & ~1) * sizeof(float) + (size_t)(c->ntaps + 1 + (to - 1) * c->down) * sizeof(float);
+            };
+            int to = 128;
+            while (to > 100 && bytes(to) > 32000) to -= 4;
+            if (bytes(to) <= 32000) TO = to;
+            if (const char *e = getenv("WH_FM_TO")) { int v = atoi(e); if (v > 96 && v <= 128 && (v & 3) == 0) TO = v; }
+        }
         if (c->ntaps + (TO - 1) * c->down <= FM_MAX_SPAN) {
             b->fused = true;
             b->TO = TO;
             b->smem = (size_t)((c->ntaps + 1) & ~1) * sizeof(float) + (size_t)(c->ntaps + 1 + (TO - 1) * c->down) * sizeof(float);
+            if (const char *e = getenv("WH_FM_EXTRA_SMEM")) b->smem += (size_t)atoi(e);   // diagnostics: occupancy sensitivity
             WH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fmbank_fused_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->smem));
         }
