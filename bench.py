@@ -189,6 +189,38 @@ def secondary_wbfm(torch, steps: int = 10):
             "x_realtime": round(0.05 / dev, 1), "cpu_port_ms_per_chunk": round(cpu * 1e3, 2), "cpu_cores": 1}
 
 
+def secondary_ddc(torch, steps: int = 20):
+    """Row N3: the trunking front-end bank -- 64 NCO + two-stage-decimator front-ends (voice-recorder plan,
+    trunking/system.py:453-656) on one 100 ms buffer of 6 MS/s IQ per call, beside the CPU port for ONE front-end."""
+    import numpy as np
+    import signals as S
+    import wavehip
+    from oracle import ref_np as O
+
+    fs, K = 6_000_000, 64
+    n = fs // 10
+    x = S.noise_c64(n, 5)
+    d = torch.from_numpy(x).cuda()
+    bank = wavehip.TrunkingDDCBank(K, fs, plan="recorder", max_samples_per_call=n)
+    offs = np.linspace(-2.0e6, 2.0e6, K)
+    for _ in range(3):
+        bank.process_device(d, offs)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        bank.process_device(d, offs)
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / steps
+    ref = O.TrunkingDDC(fs, bank.stage1_factor, bank.stage2_factor)
+    t0 = time.perf_counter()
+    ref.process(x, 250e3)
+    cpu = time.perf_counter() - t0
+    return {"workload": f"{K} trunking front-ends (NCO + {bank.stage1_factor} x {bank.stage2_factor} decimator) on 100 ms of 6 MS/s cf32 per call",
+            "ms_per_call": round(el * 1e3, 3), "x_realtime_for_the_bank": round(0.1 / el, 1),
+            "input_gsps_x_channels": round(K * n / el / 1e9, 1),
+            "cpu_port_ms_per_call_one_frontend": round(cpu * 1e3, 1), "cpu_cores": 1}
+
+
 def secondary_c4fm(torch, steps: int = 2):
     """BASELINE configs[3]: 64 P25 C4FM channels at 48 kHz, 10 s each, fed in 100 ms calls.
     Dibits of 2 channels are checked bit-exact against the C oracle in the same run."""
@@ -418,7 +450,7 @@ def main() -> None:
             line["secondary"] = {"pfb_int16": secondary_pfb_int16(torch), "pfb_m320": secondary_pfb_m320(torch),
                                  "wbfm_single": secondary_wbfm(torch),
                                  "nbfm_bank": secondary_nbfm(torch),
-                                 "c4fm_bank": secondary_c4fm(torch)}
+                                 "c4fm_bank": secondary_c4fm(torch), "ddc_bank": secondary_ddc(torch)}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
