@@ -162,7 +162,15 @@ int wh_pfb_run_i16(wh_pfb *p, const int16_t *d_iq16, size_t n_samples, float *d_
 int wh_pfb_reset(wh_pfb *p, void *stream);                       /* channelizer.py:139-142 */
 int wh_pfb_get_history(wh_pfb *p, float *h_hist /* c64[M][T] */, void *stream);
 int wh_pfb_set_history(wh_pfb *p, const float *h_hist, void *stream);
-/* measurement aid (bench.py roofline): when enabled, run() brackets the fused M=1024 kernel
+/* Explicit tuning / test switches (no reference counterpart; nothing in the library reads environment variables for
+ * these).  PATH: 0 = automatic, 1 = one-workgroup-per-hop kernel only, 2 = run kernel (one wave per run of hops),
+ * 3 = kernel shaped at compile time for this channel count; PREFETCH (M = 1024): 0 = automatic, 1 = registers,
+ * 3 = LDS DMA with counted waits; HOPS_PER_RUN: 0 = automatic. */
+#define WH_PFB_TUNE_PATH 1
+#define WH_PFB_TUNE_PREFETCH 2
+#define WH_PFB_TUNE_HOPS_PER_RUN 3
+int wh_pfb_tune(wh_pfb *p, int key, int value);
+/* measurement aid (bench.py roofline): when enabled, run() brackets the main filterbank kernel
  * with HIP events on the caller's stream; kernel_ms() waits for and returns the duration of
  * the most recent one. */
 int wh_pfb_profile(wh_pfb *p, int enable);

@@ -49,6 +49,50 @@ def test_config3_pfb_full_size_2p28():
     assert int(p.argmax()) == k and p[k].item() > 0.75 * p.sum().item()
 
 
+def test_config3_int16_dma_prefetch_full_size_bit_equal():
+    """The int16 default of the 1024-channel kernel prefetches through the LDS DMA and waits with a COUNTED vmcnt (the
+    prefetch retires, the eight younger output stores stay in flight; MI355X_MICROARCH.md: loads, stores and LDS-DMA
+    count together, in issue order) into a double-buffered LDS target.  At 2^28 samples every workgroup walks 32 groups
+    with stores in flight and the whole chip contending for HBM -- the steady state the small tests never reach -- and
+    the whole 524 287 x 1024 output plus the carried history must equal the register-prefetch kernel on the unpacked
+    copy bit for bit; a second call runs with a no-arithmetic streaming kernel co-resident on another HIP stream to
+    perturb load / store timing."""
+    import torch
+    import wavehip
+    from wavehip import _lib
+
+    n = 1 << 28
+    g = torch.Generator(device="cuda").manual_seed(44)
+    i16 = torch.randint(-12000, 12000, (2 * n,), dtype=torch.int16, device="cuda", generator=g)
+    xq = torch.view_as_complex((i16.to(torch.float32) / 32768.0).view(n, 2))    # the A1 unpack rule, exact in float32
+    dma = wavehip.PolyphaseChannelizer(10_000_000, 9765)                          # int16 input: LDS-DMA form
+    reg = wavehip.PolyphaseChannelizer(10_000_000, 9765).tune(prefetch=1)         # complex64 input, register prefetch
+    ya = dma.process_device(i16)
+    yb = reg.process_device(xq)
+    assert ya.shape == (524287, 1024) and torch.equal(ya, yb)
+    assert np.array_equal(dma.arm_history, reg.arm_history)
+    # second call (carried history) with a co-resident streaming kernel on another stream
+    side = torch.cuda.Stream()
+    m = 1 << 26
+    src = torch.view_as_complex(torch.randn(m, 2, device="cuda"))
+    dst = torch.empty(2 * m, dtype=torch.complex64, device="cuda")
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for _ in range(12):
+            _lib.check(_lib.lib.wh_diag_stream_1r2w(src.data_ptr(), dst.data_ptr(), m, _lib.stream_ptr(torch)), "diag")
+    ya = dma.process_device(i16, out=ya)
+    torch.cuda.synchronize()
+    yb = reg.process_device(xq, out=yb)
+    torch.cuda.synchronize()
+    assert torch.equal(ya, yb)
+    assert np.array_equal(dma.arm_history, reg.arm_history)
+    # the DMA form on complex64 input as well (16 KB per group through the same double buffer)
+    ya = wavehip.PolyphaseChannelizer(10_000_000, 9765).tune(prefetch=3).process_device(xq, out=ya)
+    reg.reset()
+    yb = reg.process_device(xq, out=yb)
+    assert torch.equal(ya, yb)
+
+
 def test_config2_nbfm_10s_int16_bank():
     """32 NBFM channels, 10 s of a 2.4 MS/s int16 stream in ONE launch (200 chunks): chunks are
     independent (stateless operator), so chunk c of the batch == that chunk run alone; spot-check the

@@ -682,7 +682,7 @@ def test_n2_nid_front_end(wh, golden):
     assert fe.process_batch(soft[:300], dib[:300]) == [tuple(int(v) for v in r) for r in g["events"] if r[0] < 300]
 
 
-def test_chain_wbfm_time_parallel_iir_equals_sequential(wh, golden, monkeypatch):
+def test_chain_wbfm_time_parallel_iir_equals_sequential(wh, golden):
     """The time-parallel form of the IIR rows (64 segments per row, each warmed up over the samples before it; used
     when the chain has no AGC and its impulse responses die out well inside the chunk) against the strictly
     sequential recurrence (WH_IIR_SEQ=1): same audio to ~1e-7 of peak (float32 stage rounding noise), both within
@@ -696,9 +696,7 @@ def test_chain_wbfm_time_parallel_iir_equals_sequential(wh, golden, monkeypatch)
     warm = iir_warmup_samples(stages)
     assert 1898 < warm < 4000                       # butter(5, 15 kHz @ 2.4 MS/s): slowest pole radius 0.98794, 1e-10 after 1 898 samples
     par = wh.ChannelBank(fs, n, [cfg]).process(iq)[0][0]
-    monkeypatch.setenv("WH_IIR_SEQ", "1")
-    seq = wh.ChannelBank(fs, n, [cfg]).process(iq)[0][0]
-    monkeypatch.delenv("WH_IIR_SEQ")
+    seq = wh.ChannelBank(fs, n, [cfg], iir_form="sequential").process(iq)[0][0]
     ref = g["wbfm1_audio"]
     assert peak_rel_err(par, ref) <= TOL and peak_rel_err(seq, ref) <= TOL
     assert peak_rel_err(par, seq) <= 1e-6
@@ -742,7 +740,7 @@ def test_n1_channel_dispatcher_mixed_modes(wh, golden):
     assert disp.process(iq, []) == [] and disp.process(iq[:0], cfgs) == [(None, {})] * len(cfgs)
 
 
-def test_chain_scan_form_equals_sequential(wh, monkeypatch):
+def test_chain_scan_form_equals_sequential(wh):
     """The exact scan form of the rows (zero-state pass, start states s' = M s + e, output pass; AGC envelopes
     likewise) against the strictly sequential kernel (WH_IIR_SEQ=1) at capture rate, for chains whose transition
     powers are well conditioned: AM envelope + AGC at capture rate, AM low-pass (+ AGC) at 96 kS/s.  Chains containing one of the
@@ -763,9 +761,7 @@ def test_chain_scan_form_equals_sequential(wh, monkeypatch):
         import torch
         d = torch.from_numpy(iq).cuda()
         par, mp = (t.cpu().numpy() for t in wh.ChannelBank(fs, n, [cfg]).process_device(d, 1))
-        monkeypatch.setenv("WH_IIR_SEQ", "1")
-        seq, ms = (t.cpu().numpy() for t in wh.ChannelBank(fs, n, [cfg]).process_device(d, 1))
-        monkeypatch.delenv("WH_IIR_SEQ")
+        seq, ms = (t.cpu().numpy() for t in wh.ChannelBank(fs, n, [cfg], iir_form="sequential").process_device(d, 1))
         assert np.isfinite(par).all() and peak_rel_err(par[0, 0], seq[0, 0]) <= 5e-6, (k, peak_rel_err(par[0, 0], seq[0, 0]))
         assert abs(mp[0, 0, 1] - ms[0, 0, 1]) <= 1e-4
 
@@ -836,17 +832,15 @@ def test_a7_pfb_other_channel_counts_vs_oracle(wh, O, fs, bw, M):
 
 @pytest.mark.parametrize("fs,bw,M", [(8_000_000, 25_000, 320), (1_600_000, 25_000, 64), (3_200_000, 12_500, 256),
                                       (6_400_000, 12_500, 512), (3_600_000, 12_500, 288), (2_400_000, 25_000, 96)])
-def test_a7_pfb_run_kernel_equals_per_hop_kernel(wh, fs, bw, M, monkeypatch):
-    """Channel counts 64..512 with 4 | M take the run kernel (one wave per run of hops, register windows, in-place
-    LDS passes); WH_PFB_NO_RUN=1 at construction keeps the one-workgroup-per-hop kernel.  Same pass plan and
-    arithmetic, so the outputs and the carried history must agree bit for bit -- cf32 and int16 input, ragged
+def test_a7_pfb_run_kernel_equals_per_hop_kernel(wh, fs, bw, M):
+    """Channel counts 64..512 with 4 | M and no kernel shaped for them take the run kernel (one wave per run of hops,
+    register windows, in-place LDS passes); tune(path="per_hop") keeps the one-workgroup-per-hop kernel.  Same pass plan
+    and arithmetic, so the outputs and the carried history must agree bit for bit -- cf32 and int16 input, ragged
     lengths (partial last run, odd hop counts, fewer hops than the head), four calls in a row."""
     import torch
 
-    run = wh.PolyphaseChannelizer(fs, bw)
-    monkeypatch.setenv("WH_PFB_NO_RUN", "1")
-    hop = wh.PolyphaseChannelizer(fs, bw)
-    monkeypatch.delenv("WH_PFB_NO_RUN")
+    run = wh.PolyphaseChannelizer(fs, bw).tune(path="run")
+    hop = wh.PolyphaseChannelizer(fs, bw).tune(path="per_hop")
     assert run.channel_count == M == hop.channel_count
     x = S.noise_c64(M * 700 + 99, 4000 + M, amp=0.25)
     c1 = M * 3 + 1                      # 5 hops (head only)
@@ -862,6 +856,63 @@ def test_a7_pfb_run_kernel_equals_per_hop_kernel(wh, fs, bw, M, monkeypatch):
     run.reset(); hop.reset()
     part = torch.from_numpy(i16.copy()).cuda()
     assert torch.equal(run.process_device(part), hop.process_device(part))
+
+
+SHAPED = [(8_000_000, 25_000, 320)]
+
+
+@pytest.mark.parametrize("fs,bw,M", SHAPED)
+def test_a7_pfb_shaped_kernel(wh, O, fs, bw, M):
+    """Channel counts with a kernel shaped at compile time (pfb_mid.hip; M = 320 is benchmark_dsp.py's shape): one launch
+    per call does the head hops (carried history), the runs and the history update.  Checked (i) against the oracle over
+    ragged calls (head only; one short run; many runs with a partial last one) to 1e-5, history bit-exact; (ii) against
+    the per-hop kernel (different FFT factorisation: agreement to float32 rounding); (iii) a hop's bits do not depend on
+    where the stream is cut into calls (head hops and run hops go through the same arithmetic); (iv) int16 input ==
+    unpack first, bit for bit."""
+    import torch
+
+    ch = wh.PolyphaseChannelizer(fs, bw)
+    hop = wh.PolyphaseChannelizer(fs, bw).tune(path="per_hop")
+    ref = O.PolyphaseChannelizer(fs, bw)
+    assert ch.channel_count == M
+    x = S.noise_c64(M * 700 + 99, 4100 + M, amp=0.25)
+    c1 = M * 3 + 1
+    c2 = c1 + M * 5 + M // 2
+    c3 = c2 + M * 333 + M // 2 + 7
+    cuts = [0, c1, c2, c3, len(x)]
+    pieces = []
+    worst = 0.0
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        part = torch.from_numpy(x[lo:hi].copy()).cuda()
+        ya, yb = ch.process_device(part).clone(), hop.process_device(part)
+        yr = ref.process(x[lo:hi])
+        assert tuple(ya.shape) == yr.shape == tuple(yb.shape)
+        worst = max(worst, peak_rel_err(ya.cpu().numpy(), yr))
+        assert peak_rel_err(ya.cpu().numpy(), yr) <= TOL, (M, lo, hi)
+        assert peak_rel_err(ya.cpu().numpy(), yb.cpu().numpy()) <= 2e-6, (M, lo, hi)
+        assert np.array_equal(ch.arm_history, ref.arm_history)
+        pieces.append(ya)
+    print(f"shaped M={M}: worst peak-relative error vs the oracle {worst:.2e}")
+    # cut independence: a call that starts M/2 samples after the previous call's last hop continues the stream (its
+    # history holds the stream's own blocks), so every hop must equal the one-call result bit for bit
+    one, two = wh.PolyphaseChannelizer(fs, bw), wh.PolyphaseChannelizer(fs, bw)
+    HB, n_hops = M // 2, 900
+    xd = torch.from_numpy(x[: HB * (n_hops - 1) + M].copy()).cuda()
+    whole = one.process_device(xd).clone()
+    assert whole.shape[0] == n_hops
+    h0 = 0
+    for cnt in (3, 11, 516, 370):
+        seg = two.process_device(xd[h0 * HB: (h0 + cnt - 1) * HB + M])
+        assert torch.equal(seg, whole[h0: h0 + cnt]), (M, h0, cnt)
+        h0 += cnt
+    assert np.array_equal(one.arm_history, two.arm_history)
+    # int16 input
+    i16 = S.pack_iq16_np(x[: M * 150 + 11])
+    xq = torch.from_numpy(wh.unpack_iq16(i16)).cuda()
+    a, b = wh.PolyphaseChannelizer(fs, bw), wh.PolyphaseChannelizer(fs, bw)
+    ya = a.process_device(torch.from_numpy(i16.copy()).cuda())
+    yb = b.process_device(xq)
+    assert torch.equal(ya, yb) and np.array_equal(a.arm_history, b.arm_history)
 
 
 @pytest.mark.parametrize("fs,bw,M,T", [(8_000_000, 25_000, 320, 5), (8_000_000, 25_000, 320, 12),
@@ -881,9 +932,9 @@ def test_a7_pfb_other_tap_counts_vs_oracle(wh, O, fs, bw, M, T):
     assert np.array_equal(ch.arm_history, ref.arm_history)
 
 
-def test_a7_pfb_prefetch_forms_agree(wh, monkeypatch):
+def test_a7_pfb_prefetch_forms_agree(wh):
     """The fused 1024-channel kernel prefetches the next group's samples either into registers (complex64 default) or
-    through the LDS DMA with counted waits (int16 default); WH_PFB_VARIANT = 1 / 3 forces one form for both formats.
+    through the LDS DMA with counted waits (int16 default); tune(prefetch=1 / 3) forces one form for both formats.
     Same arithmetic, so all four (format, form) pairs agree bit for bit, ragged tail and second call included."""
     import torch
 
@@ -892,12 +943,11 @@ def test_a7_pfb_prefetch_forms_agree(wh, monkeypatch):
     xq = torch.from_numpy(wh.unpack_iq16(S.pack_iq16_np(x))).cuda()
     outs = {}
     for v in ("1", "3"):
-        monkeypatch.setenv("WH_PFB_VARIANT", v)
-        a, b = wh.PolyphaseChannelizer(10_000_000, 9765), wh.PolyphaseChannelizer(10_000_000, 9765)
+        a = wh.PolyphaseChannelizer(10_000_000, 9765).tune(prefetch=int(v))
+        b = wh.PolyphaseChannelizer(10_000_000, 9765).tune(prefetch=int(v))
         cut = 1024 * 150 + 512
         outs[v] = [torch.cat([a.process_device(xq[:cut]), a.process_device(xq[cut:])]),
                    torch.cat([b.process_device(i16[:2 * cut]), b.process_device(i16[2 * cut:])])]
-    monkeypatch.delenv("WH_PFB_VARIANT")
     ref = outs["1"][0]
     assert all(torch.equal(ref, o) for v in outs for o in outs[v])
 

@@ -1217,14 +1217,10 @@ __global__ __launch_bounds__(256) void nr_norm_kernel(float *rows, int N, int F,
 
 // tiles per workgroup of the fused FM kernel: as long as the launch keeps >= ~4096 workgroups (16 per CU) longer
 // runs only save work (less window overlap recomputed); a single live chunk of a few channels stays at one tile per
-// workgroup.  Tiles are spread evenly over the runs.  WH_FM_RUN overrides (diagnostics).
+// workgroup.  Tiles are spread evenly over the runs.
 static int run_tiles(int tiles, size_t rows) {
     size_t total = (size_t)tiles * rows;
     int R = (int)(total / 4096 < 1 ? 1 : (total / 4096 > (size_t)tiles ? (size_t)tiles : total / 4096));
-    if (const char *e = getenv("WH_FM_RUN")) {
-        int v = atoi(e);
-        if (v >= 1) R = v;
-    }
     if (R > tiles) R = tiles;
     if (R < 1) R = 1;
     const int runs = (tiles + R - 1) / R;
@@ -1383,20 +1379,18 @@ extern "C" int wh_chanbank_create(wh_chanbank **out, const wh_chanbank_cfg *c) {
         // 1001 taps at 50:1 (33.4 KB): a few outputs fewer per tile fit 5, and the launch is occupancy-sensitive (2 / 3 /
         // 4 workgroups per CU: 4.07 / 2.96 / 2.48 ms).  Measured: 124 outputs (32.6 KB) still runs 4 per CU, 120
         // (31.8 KB) runs 5: 2.48 -> 2.35 ms; 116 / 112 give the gain back to emptier tiles.
-        if (TO == 128 && (c->down & 1) == 0 && !getenv("WH_FM_TO128")) {
+        if (TO == 128 && (c->down & 1) == 0) {
             auto bytes = [&](int to) {
                 return (size_t)((c->ntaps + 1) & ~1) * sizeof(float) + (size_t)(c->ntaps + 1 + (to - 1) * c->down) * sizeof(float);
             };
             int to = 128;
             while (to > 100 && bytes(to) > 32000) to -= 4;
             if (bytes(to) <= 32000) TO = to;
-            if (const char *e = getenv("WH_FM_TO")) { int v = atoi(e); if (v > 96 && v <= 128 && (v & 3) == 0) TO = v; }
         }
         if (c->ntaps + (TO - 1) * c->down <= FM_MAX_SPAN) {
             b->fused = true;
             b->TO = TO;
             b->smem = (size_t)((c->ntaps + 1) & ~1) * sizeof(float) + (size_t)(c->ntaps + 1 + (TO - 1) * c->down) * sizeof(float);
-            if (const char *e = getenv("WH_FM_EXTRA_SMEM")) b->smem += (size_t)atoi(e);   // diagnostics: occupancy sensitivity
             WH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fmbank_fused_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->smem));
         }
@@ -1509,13 +1503,10 @@ extern "C" int wh_chanbank_run(wh_chanbank *b, const void *d_in, size_t n_chunks
                     // (chains of more than 3 stages keep one wave per row: their state alone is 20 VGPRs per stage)
                     rw = c.n_stages > 3 ? 1 : c.n_channels <= 16 ? ROWS_MAXW : c.n_channels <= 64 ? 4 : 1;
                     while (rw > 1 && c.chunk_len < 64 * rw * 16) rw >>= 1;
-                    if (const char *e = getenv("WH_ROWS_WAVES")) { int v = atoi(e); if (c.n_stages <= 3 && (v == 1 || v == 2 || v == 4 || v == 8)) rw = v; }
                     seg = (c.chunk_len + 64 * rw - 1) / (64 * rw);
                 }
             }
-            const bool force_seq = getenv("WH_IIR_SEQ") != nullptr;   // diagnostics: force the sequential form
-            if (force_seq) seg = 0;
-            if (b->scan_seg && !force_seq) {
+            if (b->scan_seg) {
                 hipLaunchKernelGGL(chan_rows_scan_kernel, dim3((unsigned)rows), dim3(64), 0, st, a.fm_out, b->d_acc, c.chunk_len,
                                    b->stages, c.n_stages, g, b->scan_seg, b->d_pow);
                 WH_LAUNCH_CHECK();

@@ -20,6 +20,7 @@
 // Generic path (any even M): one workgroup per hop, MAC into LDS, then mixed-radix (4/2/3/5) Stockham passes in LDS,
 // or the direct DFT for a count with another prime factor.  Also used for the first T-1 hops of every call (they
 // read the carried history) and the tail hops of the fast path.
+#include "pfb_internal.h"
 #include "wh_common.h"
 #include <cmath>
 #include <cstdint>
@@ -61,7 +62,9 @@ struct PfbFastArgs {
     long long n_groups;     // total groups of GH hops
     int groups_per_wg;
     int n_wg;
-    int ablate;             // diagnostics only (WH_PFB_ABLATE): 1 = suppress stores
+#ifdef WH_DIAG
+    int ablate;             // diagnostics build only (WH_PFB_ABLATE): 1 = suppress stores
+#endif
 };
 
 // GLDS: the next group's samples are prefetched into LDS by the DMA path (global_load_lds, inline asm: no register
@@ -72,9 +75,12 @@ struct PfbFastArgs {
 template <int FMT, bool GLDS = false>
 __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
     constexpr int PRE_BYTES = GLDS ? GH * FHOP * (FMT == 1 ? 4 : 8) : 0;   // GH half-blocks of samples
-    __shared__ __attribute__((aligned(16))) float2 lds[GH * LDS_HOP + 256 + PRE_BYTES / 8];
+    // the DMA target is double-buffered: the copy for group g+2 is issued by whichever wave finishes group g+1's arm MAC
+    // first, and lands while slower waves may still be reading group g+1's samples -- it must not share their buffer.
+    // With two buffers a buffer is rewritten only after a workgroup barrier that follows its last reads.
+    __shared__ __attribute__((aligned(16))) float2 lds[GH * LDS_HOP + 256 + 2 * PRE_BYTES / 8];
     float2 *tw256 = lds + GH * LDS_HOP;
-    unsigned char *pre = reinterpret_cast<unsigned char *>(lds + GH * LDS_HOP + 256);
+    unsigned char *pre0 = reinterpret_cast<unsigned char *>(lds + GH * LDS_HOP + 256);
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -123,6 +129,7 @@ __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
     if (GLDS) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the window fill is complete before the loop, so that no
                                                     // wait for it is placed inside the loop (it would drain the stores)
     for (long long g = g0; g < g1; ++g, h += GH) {
+        unsigned char *pre = pre0 + (((g - g0) & 1) ? PRE_BYTES : 0);   // buffer of the copy issued in this iteration
         // ---- arm MAC + radix-4 stage for GH hops --------------------------------------------
 #pragma unroll
         for (int i = 0; i < GH; ++i) {
@@ -256,15 +263,22 @@ __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
                     rcv.y = __shfl_xor(snd.y, 1);
                     float2 lo = even ? v[j] : rcv;
                     float2 hi = even ? rcv : v[j + 8];
-                    if (a.ablate != 1 || lo.x == 1.2345e30f) o4[32 * j] = make_float4(lo.x, lo.y, hi.x, hi.y);
+#ifdef WH_DIAG
+                    if (a.ablate != 1 || lo.x == 1.2345e30f)
+#endif
+                    o4[32 * j] = make_float4(lo.x, lo.y, hi.x, hi.y);
                 }
             }
         }
         if (GLDS) {
-            // the prefetch is older than this group's 8 stores: retire it, keep them in flight (no stores in the
-            // diagnostic no-store mode: then wait for everything)
+            // the prefetch is older than this group's 8 stores: retire it, keep them in flight.  vmcnt counts loads,
+            // stores and LDS-DMA together, in issue order (MI355X_MICROARCH.md, "s_waitcnt vmcnt(N) waits until all
+            // but the wave's N youngest vector-memory operations are done"); tools/ubench/vmcnt_order.hip checks it
+#ifdef WH_DIAG
             if (a.ablate) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else
+#endif
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         }
         __syncthreads();
         if (GLDS && g + 1 < g1) {
@@ -781,10 +795,12 @@ struct wh_pfb {
     int cur = 0;
     double *d_part = nullptr;   // stats partials
     int cu_count = 256;
-    int gpw_override = 0;       // tuning knob (WH_PFB_GPW)
-    int ablate = 0;             // diagnostics (WH_PFB_ABLATE)
-    int variant = 0;            // WH_PFB_VARIANT (diagnostics): 1 = register prefetch, 3 = LDS-DMA prefetch, for both formats
+    int gpw_override = 0;       // wh_pfb_tune(WH_PFB_TUNE_HOPS_PER_RUN)
+    int ablate = 0;             // diagnostics build only (WH_PFB_ABLATE)
+    int variant = 0;            // wh_pfb_tune(WH_PFB_TUNE_PREFETCH): 1 = register prefetch, 3 = LDS-DMA prefetch, for both formats
+    int path = 0;               // wh_pfb_tune(WH_PFB_TUNE_PATH): 0 auto, 1 per-hop kernel only, 2 run kernel, 3 shaped kernel
     bool run_ok = false;        // M, T fit pfb_run_kernel
+    bool mid_ok = false;        // a compile-time-shaped instance exists (pfb_mid.hip)
     bool prof = false;          // bracket the fused kernel with events (bench roofline)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
@@ -796,9 +812,9 @@ extern "C" int wh_pfb_create(wh_pfb **out, int M, int T, const double *h_arms) {
     wh_pfb *p = new wh_pfb();
     std::unique_ptr<wh_pfb, void (*)(wh_pfb *)> guard(p, wh_pfb_destroy);  // frees partial state on early return
     p->M = M; p->T = T;
-    if (const char *e = getenv("WH_PFB_GPW")) p->gpw_override = atoi(e);
+#ifdef WH_DIAG
     if (const char *e = getenv("WH_PFB_ABLATE")) p->ablate = atoi(e);
-    if (const char *e = getenv("WH_PFB_VARIANT")) p->variant = atoi(e);
+#endif
     int l2 = 0;
     while ((1 << l2) < M) ++l2;
     p->log2M = ((1 << l2) == M) ? l2 : 0;
@@ -807,8 +823,9 @@ extern "C" int wh_pfb_create(wh_pfb **out, int M, int T, const double *h_arms) {
         while (rem % 2 == 0) rem /= 2;
         while (rem % 3 == 0) rem /= 3;
         while (rem % 5 == 0) rem /= 5;
-        p->run_ok = T == RT && M % 4 == 0 && M >= 64 && M <= 512 && M != FM && rem == 1 && !getenv("WH_PFB_NO_RUN");
+        p->run_ok = T == RT && M % 4 == 0 && M >= 64 && M <= 512 && M != FM && rem == 1;
     }
+    p->mid_ok = pfb_mid_supported(M, T);
     std::vector<float> arms((size_t)M * T);
     for (size_t i = 0; i < arms.size(); ++i) arms[i] = (float)h_arms[i];
     std::vector<float2> tw(M);
@@ -844,6 +861,27 @@ extern "C" void wh_pfb_destroy(wh_pfb *p) {
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
     delete p;
+}
+
+extern "C" int wh_pfb_tune(wh_pfb *p, int key, int value) {
+    if (!p) return set_err(WH_E_ARG, "wh_pfb_tune: null handle");
+    switch (key) {
+    case WH_PFB_TUNE_PATH:
+        if (value < 0 || value > 3) return set_err(WH_E_ARG, "wh_pfb_tune: path %d", value);
+        if (value == 2 && !p->run_ok) return set_err(WH_E_ARG, "wh_pfb_tune: the run kernel does not take M=%d T=%d", p->M, p->T);
+        if (value == 3 && !p->mid_ok) return set_err(WH_E_ARG, "wh_pfb_tune: no shaped kernel for M=%d T=%d", p->M, p->T);
+        p->path = value;
+        return WH_OK;
+    case WH_PFB_TUNE_PREFETCH:
+        if (value != 0 && value != 1 && value != 3) return set_err(WH_E_ARG, "wh_pfb_tune: prefetch %d", value);
+        p->variant = value;
+        return WH_OK;
+    case WH_PFB_TUNE_HOPS_PER_RUN:
+        if (value < 0 || value > 4096) return set_err(WH_E_ARG, "wh_pfb_tune: hops per run %d", value);
+        p->gpw_override = value;
+        return WH_OK;
+    }
+    return set_err(WH_E_ARG, "wh_pfb_tune: unknown key %d", key);
 }
 
 extern "C" int wh_pfb_profile(wh_pfb *p, int enable) {
@@ -894,7 +932,7 @@ static int launch_generic(wh_pfb *p, const void *d_iq, int fmt, float *d_out, lo
         while (rem % 2 == 0 && k < 16) { rad[k++] = 2; rem /= 2; }
         while (rem % 3 == 0 && k < 16) { rad[k++] = 3; rem /= 3; }
         while (rem % 5 == 0 && k < 16) { rad[k++] = 5; rem /= 5; }
-        if (rem == 1 && k > 0 && !getenv("WH_PFB_NO_MIXED_RADIX")) {
+        if (rem == 1 && k > 0) {
             a.n_radix = k;
             for (int i = 0; i < 16; ++i) a.radix[i] = i < k ? rad[i] : 1;
         } else {
@@ -907,10 +945,9 @@ static int launch_generic(wh_pfb *p, const void *d_iq, int fmt, float *d_out, lo
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     }
     // block size: small channel counts are latency-bound per workgroup (a few hundred points, barriers between
-    // passes), so fewer threads per hop and more hops in flight per CU win; WH_PFB_GEN_THREADS overrides
+    // passes), so fewer threads per hop and more hops in flight per CU win
     int bt = p->M <= 512 ? 64 : 256;
     if (n_hops + n_hops_b <= 2LL * p->cu_count) bt = 256;   // a handful of hops (head of a run-kernel call): latency only
-    if (const char *e = getenv("WH_PFB_GEN_THREADS")) { int v = atoi(e); if (v == 64 || v == 128 || v == 256) bt = v; }
     // grid.x is limited to 2^31-1; chunk very long tails (never happens for the fast path)
     const long long MAXG = 1 << 30;
     if (n_hops_b > 0) {   // two short ranges in one launch
@@ -945,8 +982,25 @@ static int pfb_run_fmt(wh_pfb *p, const void *d_iq, int fmt, size_t n, float *d_
     if (H == 0) return WH_OK;
     if (!d_iq || !d_out) return set_err(WH_E_ARG, "wh_pfb_run: null buffer");
     int rc;
-    const bool fast = (p->M == FM && p->T == FT);
-    const bool run = !fast && p->run_ok;
+    const bool fast = (p->M == FM && p->T == FT) && p->path != 1;
+    if (!fast && p->mid_ok && (p->path == 0 || p->path == 3)) {
+        // one launch: head hops, runs and the history update (pfb_mid.hip)
+        PfbMidCall c;
+        c.x = d_iq; c.fmt = fmt; c.n = n;
+        c.hist = p->d_hist[p->cur]; c.new_hist = p->d_hist[p->cur ^ 1];
+        c.out = reinterpret_cast<float2 *>(d_out);
+        c.arms = p->d_arms; c.tw = p->d_tw;
+        c.H = H; c.cu_count = p->cu_count; c.hops_per_run = p->gpw_override; c.stats_only = 0;
+        if (p->prof) WH_HIP(hipEventRecord(p->ev0, st));
+        if ((rc = pfb_mid_launch(p->M, p->T, c, st)) != WH_OK) return rc;
+        if (p->prof) {
+            WH_HIP(hipEventRecord(p->ev1, st));
+            p->ev_valid = true;
+        }
+        p->cur ^= 1;
+        return WH_OK;
+    }
+    const bool run = !fast && p->run_ok && p->path != 1;
     long long head = (fast || run) ? (H < 8 ? H : 8) : H;
     {
         // head hops (need the carried history) + the <= 3 ragged tail hops of the fast path, one launch
@@ -1030,7 +1084,9 @@ static int pfb_run_fmt(wh_pfb *p, const void *d_iq, int fmt, size_t n, float *d_
             }
             a.groups_per_wg = gpw;
             a.n_wg = (int)nwg;
+#ifdef WH_DIAG
             a.ablate = p->ablate;
+#endif
             if (p->prof) WH_HIP(hipEventRecord(p->ev0, st));
             // prefetch path: int16 input through the LDS DMA (16 bytes per lane instead of 4: 1.30 -> 1.15 ms per 2^28
             // samples), complex64 input through registers (the DMA detour costs it 4 %); WH_PFB_VARIANT = 1 / 3 forces
@@ -1099,8 +1155,10 @@ extern "C" int wh_diag_stream_1r2w(const float *d_in, float *d_out, size_t n, vo
     size_t blocks = (n4 + 1023) / 1024;
     size_t cap = (size_t)1 << 24;   // one pass per workgroup measured best (5.4 TB/s; 4.9 with a 4096-block grid-stride walk)
     int mode = 0;
+#ifdef WH_DIAG
     if (const char *e = getenv("WH_DIAG_BLOCKS")) cap = (size_t)atol(e);
     if (const char *e = getenv("WH_DIAG_MODE")) mode = atoi(e);
+#endif
     if (blocks > cap) blocks = cap;
     const float4 *in4 = reinterpret_cast<const float4 *>(d_in);
     float4 *out4 = reinterpret_cast<float4 *>(d_out);

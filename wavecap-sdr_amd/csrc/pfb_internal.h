@@ -1,0 +1,30 @@
+// Internal (not exported) interface between pfb.hip (handle, C ABI) and pfb_mid.hip (the compile-time-shaped
+// filterbank kernels for the mid-size / large channel counts).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace wh {
+
+struct PfbMidCall {
+    const void *x;           // input samples (complex64, or interleaved int16 IQ when fmt == 1)
+    int fmt;
+    size_t n;                // samples in this call
+    const float2 *hist;      // [M][T] carried history (column j = block_{-1-j}); read
+    float2 *new_hist;        // [M][T] history after this call; written
+    float2 *out;             // [H][M]
+    const float *arms;       // float32 [M][T]
+    const float2 *tw;        // exp(-2 pi i m / M), m in [0, M)
+    long long H;             // hops of this call (> 0)
+    int cu_count;
+    int hops_per_run;        // 0 = choose; tuning override otherwise
+    int stats_only;          // 1: do not store the channel outputs (statistics epilogue only; reserved)
+};
+
+// true when a compiled instance exists for (M, T)
+bool pfb_mid_supported(int M, int T);
+// one launch: head hops (carried history), the runs, and the history update.  Returns a WH_* status.
+int pfb_mid_launch(int M, int T, const PfbMidCall &c, hipStream_t st);
+// kernel name fragment for profiles / bench reporting
+const char *pfb_mid_kernel_name();
+
+}  // namespace wh

@@ -256,10 +256,11 @@ class ChannelBank:
     """All channels of one capture that share one chain (mode + filter settings + audio rate)."""
 
     def __init__(self, sample_rate: int, chunk_len: int, cfgs: list, input_format: str = "cf32",
-                 apply_squelch: bool = False):
+                 apply_squelch: bool = False, iir_form: str = "auto"):
         """apply_squelch=True additionally zeroes the audio of chunks whose rssi_db is below the channel's
         squelch_db (capture.py:2918-2921; in the reference that happens later, in _apply_stateful_processing,
-        so the drop-in for _process_channel_dsp_stateless leaves it off)."""
+        so the drop-in for _process_channel_dsp_stateless leaves it off).  iir_form="sequential" keeps the IIR stages
+        on the one-lane-per-row recurrence (tests compare the parallel forms against it)."""
         if not cfgs:
             raise ValueError("ChannelBank needs at least one channel")
         for c in cfgs:
@@ -290,8 +291,11 @@ class ChannelBank:
             cfg.pll_alpha, cfg.pll_beta = sam_pll_coefficients(self.sample_rate, float(getattr(c0, "sam_pll_bandwidth_hz", 50.0)))
         keep = [offs]
         cfg.n_stages = len(stages)
-        cfg.iir_warmup = iir_warmup_samples(stages) if (stages and agc is None and demod < 3) else 0
-        cfg.iir_scan = 1 if iir_scan_safe(stages, (self.chunk_len + 63) // 64) else 0
+        if iir_form not in ("auto", "sequential"):
+            raise ValueError("iir_form must be 'auto' or 'sequential'")
+        par = iir_form == "auto"
+        cfg.iir_warmup = iir_warmup_samples(stages) if (par and stages and agc is None and demod < 3) else 0
+        cfg.iir_scan = 1 if (par and iir_scan_safe(stages, (self.chunk_len + 63) // 64)) else 0
         if stages:
             arr = (_lib.IirStage * len(stages))(*stages)
             cfg.h_stages = arr

@@ -108,6 +108,18 @@ class PolyphaseChannelizer:
         d = torch.from_numpy(x).cuda()
         return self.process_device(d).cpu().numpy()
 
+    TUNE_KEYS = {"path": 1, "prefetch": 2, "hops_per_run": 3}
+    PATHS = {"auto": 0, "per_hop": 1, "run": 2, "shaped": 3}
+
+    def tune(self, **kw) -> "PolyphaseChannelizer":
+        """Explicit kernel selection for tests / measurements (wh_pfb_tune): path="auto"|"per_hop"|"run"|"shaped",
+        prefetch=0|1|3, hops_per_run=int."""
+        for k, v in kw.items():
+            if k == "path" and isinstance(v, str):
+                v = self.PATHS[v]
+            _lib.check(_lib.lib.wh_pfb_tune(self._h, self.TUNE_KEYS[k], int(v)), "wh_pfb_tune")
+        return self
+
     def profile(self, enable: bool = True) -> None:
         _lib.check(_lib.lib.wh_pfb_profile(self._h, 1 if enable else 0), "wh_pfb_profile")
 
