@@ -794,6 +794,7 @@ struct wh_pfb {
     float2 *d_hist[2] = {nullptr, nullptr};
     int cur = 0;
     double *d_part = nullptr;   // stats partials
+    float2 *d_sink = nullptr;   // [M] write-only scratch row of the shaped kernels
     int cu_count = 256;
     int gpw_override = 0;       // wh_pfb_tune(WH_PFB_TUNE_HOPS_PER_RUN)
     int ablate = 0;             // diagnostics build only (WH_PFB_ABLATE)
@@ -843,6 +844,7 @@ extern "C" int wh_pfb_create(wh_pfb **out, int M, int T, const double *h_arms) {
     WH_HIP(hipMalloc(&p->d_hist[0], (size_t)M * T * sizeof(float2)));
     WH_HIP(hipMalloc(&p->d_hist[1], (size_t)M * T * sizeof(float2)));
     WH_HIP(hipMalloc(&p->d_part, (size_t)64 * M * 4 * sizeof(double)));
+    WH_HIP(hipMalloc(&p->d_sink, (size_t)M * sizeof(float2)));
     WH_HIP(hipMemcpy(p->d_arms, arms.data(), arms.size() * sizeof(float), hipMemcpyHostToDevice));
     WH_HIP(hipMemcpy(p->d_tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice));
     WH_HIP(hipMemset(p->d_hist[0], 0, (size_t)M * T * sizeof(float2)));
@@ -858,6 +860,7 @@ extern "C" void wh_pfb_destroy(wh_pfb *p) {
     (void)hipFree(p->d_hist[0]);
     (void)hipFree(p->d_hist[1]);
     (void)hipFree(p->d_part);
+    (void)hipFree(p->d_sink);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
     delete p;
@@ -876,6 +879,11 @@ extern "C" int wh_pfb_tune(wh_pfb *p, int key, int value) {
         if (value != 0 && value != 1 && value != 3) return set_err(WH_E_ARG, "wh_pfb_tune: prefetch %d", value);
         p->variant = value;
         return WH_OK;
+#ifdef WH_DIAG
+    case 4:   // diagnostics build only: ablation bits of the shaped kernel
+        p->ablate = value;
+        return WH_OK;
+#endif
     case WH_PFB_TUNE_HOPS_PER_RUN:
         if (value < 0 || value > 4096) return set_err(WH_E_ARG, "wh_pfb_tune: hops per run %d", value);
         p->gpw_override = value;
@@ -989,8 +997,12 @@ static int pfb_run_fmt(wh_pfb *p, const void *d_iq, int fmt, size_t n, float *d_
         c.x = d_iq; c.fmt = fmt; c.n = n;
         c.hist = p->d_hist[p->cur]; c.new_hist = p->d_hist[p->cur ^ 1];
         c.out = reinterpret_cast<float2 *>(d_out);
+        c.sink = p->d_sink;
         c.arms = p->d_arms; c.tw = p->d_tw;
         c.H = H; c.cu_count = p->cu_count; c.hops_per_run = p->gpw_override; c.stats_only = 0;
+#ifdef WH_DIAG
+        c.stats_only = p->ablate << 8;
+#endif
         if (p->prof) WH_HIP(hipEventRecord(p->ev0, st));
         if ((rc = pfb_mid_launch(p->M, p->T, c, st)) != WH_OK) return rc;
         if (p->prof) {

@@ -12,6 +12,7 @@ struct PfbMidCall {
     const float2 *hist;      // [M][T] carried history (column j = block_{-1-j}); read
     float2 *new_hist;        // [M][T] history after this call; written
     float2 *out;             // [H][M]
+    float2 *sink;            // [M] scratch row nobody reads (stores of hops past the end of the call)
     const float *arms;       // float32 [M][T]
     const float2 *tw;        // exp(-2 pi i m / M), m in [0, M)
     long long H;             // hops of this call (> 0)

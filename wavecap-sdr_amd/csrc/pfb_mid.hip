@@ -66,62 +66,89 @@ constexpr MidPlan mid_plan(int Q) {
 }
 
 template <int FMT>
-__device__ __forceinline__ float2 ld_iq(const void *p, long long i) {
+__device__ __forceinline__ v2f ld_iq(const void *p, long long i) {
     if (FMT == 1) {   // A1 unpack rule (cli.py:447-452): int16 / 32768
-        short2 v = reinterpret_cast<const short2 *>(p)[i];
-        return make_float2((float)v.x * (1.0f / 32768.0f), (float)v.y * (1.0f / 32768.0f));
+        const short2 v = reinterpret_cast<const short2 *>(p)[i];
+        return v2f{(float)v.x * (1.0f / 32768.0f), (float)v.y * (1.0f / 32768.0f)};
     }
-    return reinterpret_cast<const float2 *>(p)[i];
+    return reinterpret_cast<const v2f *>(p)[i];
 }
+
+// complex arithmetic on packed pairs: every line below is one v_pk_* instruction (swaps, broadcasts and sign patterns
+// fold into op_sel / constant operands); the float2 helpers of wh_common.h compile to 1.5-2x as many instructions
+#define WH_SW(a) __builtin_shufflevector(a, a, 1, 0)
+#define WH_XX(a) __builtin_shufflevector(a, a, 0, 0)
+#define WH_YY(a) __builtin_shufflevector(a, a, 1, 1)
+#define WH_FMA(a, b, c) __builtin_elementwise_fma(a, b, c)
+__device__ __forceinline__ v2f bc(float c) { return v2f{c, c}; }
+// a * w with w = (wx, wy)
+__device__ __forceinline__ v2f cmul3(v2f a, v2f w) {
+    const v2f t = WH_XX(a) * w;
+    const v2f s = WH_YY(a) * v2f{-1.f, 1.f};   // (-ay, ay)
+    return WH_FMA(s, WH_SW(w), t);
+}
+// a * w with the table entry w4 = (wx, wy, -wy, wx)
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v2f cmul2(v2f a, v4f w4) {
+    const v2f t = WH_XX(a) * __builtin_shufflevector(w4, w4, 0, 1);
+    return WH_FMA(WH_YY(a), __builtin_shufflevector(w4, w4, 2, 3), t);
+}
+// x + (-i) d and x - (-i) d:  (-i) d = (d.y, -d.x)
+#define WH_PMI(x, d) WH_FMA(WH_SW(d), (v2f{1.f, -1.f}), x)
+#define WH_MMI(x, d) WH_FMA(WH_SW(d), (v2f{-1.f, 1.f}), x)
 
 // forward butterflies, natural order in and out
-__device__ __forceinline__ void bfly(float2 (&v)[2]) {
-    float2 a = v[0], b = v[1];
-    v[0] = cadd(a, b);
-    v[1] = csub(a, b);
+__device__ __forceinline__ void bfly(v2f (&v)[2]) {
+    const v2f a = v[0], b = v[1];
+    v[0] = a + b;
+    v[1] = a - b;
 }
-__device__ __forceinline__ void bfly(float2 (&v)[3]) {
-    const float C = -0.5f, S = -0.86602540378443864676f;   // exp(-2 pi i / 3)
-    float2 t1 = cadd(v[1], v[2]), t2 = csub(v[1], v[2]);
-    float2 u = make_float2(fmaf(C, t1.x, v[0].x), fmaf(C, t1.y, v[0].y));
-    float2 w = make_float2(-S * t2.y, S * t2.x);            // i * S * t2
-    v[0] = cadd(v[0], t1);
-    v[1] = cadd(u, w);
-    v[2] = csub(u, w);
+__device__ __forceinline__ void bfly(v2f (&v)[3]) {
+    const float S = 0.86602540378443864676f;   // exp(-2 pi i / 3) = -1/2 - i S
+    const v2f t1 = v[1] + v[2], t2 = v[1] - v[2];
+    const v2f u = WH_FMA(t1, bc(-0.5f), v[0]);
+    v[0] = v[0] + t1;
+    v[1] = WH_FMA(WH_SW(t2), (v2f{S, -S}), u);    // u + (-i S) t2
+    v[2] = WH_FMA(WH_SW(t2), (v2f{-S, S}), u);
 }
-__device__ __forceinline__ void bfly(float2 (&v)[4]) { fft4(v[0], v[1], v[2], v[3]); }
-__device__ __forceinline__ void bfly(float2 (&v)[5]) {
+__device__ __forceinline__ void bfly(v2f (&v)[4]) {
+    const v2f s02 = v[0] + v[2], d02 = v[0] - v[2], s13 = v[1] + v[3], d13 = v[1] - v[3];
+    v[0] = s02 + s13;
+    v[2] = s02 - s13;
+    v[1] = WH_PMI(d02, d13);
+    v[3] = WH_MMI(d02, d13);
+}
+__device__ __forceinline__ void bfly(v2f (&v)[5]) {
     const float C1 = 0.30901699437494742410f, S1 = 0.95105651629515357212f;    // cos, sin 2 pi / 5
     const float C2 = -0.80901699437494742410f, S2 = 0.58778525229247312917f;   // cos, sin 4 pi / 5
-    float2 v0 = v[0];
-    float2 a1 = cadd(v[1], v[4]), b1 = csub(v[1], v[4]), a2 = cadd(v[2], v[3]), b2 = csub(v[2], v[3]);
-    float2 r1 = make_float2(fmaf(C2, a2.x, fmaf(C1, a1.x, v0.x)), fmaf(C2, a2.y, fmaf(C1, a1.y, v0.y)));
-    float2 r2 = make_float2(fmaf(C1, a2.x, fmaf(C2, a1.x, v0.x)), fmaf(C1, a2.y, fmaf(C2, a1.y, v0.y)));
-    // -i (S1 b1 + S2 b2), -i (S2 b1 - S1 b2)   (forward transform)
-    float2 i1 = make_float2(fmaf(S2, b2.y, S1 * b1.y), -fmaf(S2, b2.x, S1 * b1.x));
-    float2 i2 = make_float2(fmaf(-S1, b2.y, S2 * b1.y), -fmaf(-S1, b2.x, S2 * b1.x));
-    v[0] = make_float2(v0.x + a1.x + a2.x, v0.y + a1.y + a2.y);
-    v[1] = cadd(r1, i1);
-    v[2] = cadd(r2, i2);
-    v[3] = csub(r2, i2);
-    v[4] = csub(r1, i1);
+    const v2f v0 = v[0];
+    const v2f a1 = v[1] + v[4], b1 = v[1] - v[4], a2 = v[2] + v[3], b2 = v[2] - v[3];
+    const v2f r1 = WH_FMA(a2, bc(C2), WH_FMA(a1, bc(C1), v0));
+    const v2f r2 = WH_FMA(a2, bc(C1), WH_FMA(a1, bc(C2), v0));
+    const v2f t1 = WH_FMA(b2, bc(S2), b1 * bc(S1));
+    const v2f t2 = WH_FMA(b2, bc(-S1), b1 * bc(S2));
+    v[0] = v0 + a1 + a2;
+    v[1] = WH_PMI(r1, t1);
+    v[4] = WH_MMI(r1, t1);
+    v[2] = WH_PMI(r2, t2);
+    v[3] = WH_MMI(r2, t2);
 }
 
-// packed FMA with one float of a tap PAIR broadcast to both halves (op_sel): (re, im) * tap + acc as one instruction,
-// with the 36 taps of a quad in 18 register pairs.  Written as the compiler would for a {t, t} operand, it keeps a
-// duplicated copy of every tap (72 registers).
+// (re, im) * tap + acc as one packed FMA, the tap being one half of a register PAIR of taps (the shuffle folds into the
+// instruction's op_sel bits): the 36 taps of a quad take 18 register pairs.  From separate scalars the compiler keeps a
+// duplicated {t, t} pair per tap (72 registers).
 __device__ __forceinline__ v2f pk_fma_bc(int hi, v2f a, v2f tpair, v2f c) {   // hi: constant after unrolling
-    v2f d;
-    if (hi) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "v"(tpair), "v"(c));
-    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(tpair), "v"(c));
-    return d;
+    return WH_FMA(a, hi ? WH_YY(tpair) : WH_XX(tpair), c);
 }
 
 struct MidArgs {
     const void *x;
-    const float2 *hist;
-    float2 *new_hist;
-    float2 *out;
+    const v2f *hist;
+    v2f *new_hist;
+    v2f *out;
+    v2f *sink;             // M complex nobody reads: the stores of hops past the end of the call go here, so that every
+                           // wave issues the same number of stores per group and the compiler can wait for the next
+                           // group's prefetched samples with a COUNTED vmcnt (its stores stay in flight)
     const float *arms;
     const float2 *tw;
     long long H;           // hops of the call
@@ -129,15 +156,107 @@ struct MidArgs {
     long long max_block;   // last half-block index fully inside the input
     int hpr;               // hops per run (multiple of GH)
     int n_head;            // workgroups [0, n_head) do the head hops, workgroup n_head the history, the rest the runs
+#ifdef WH_DIAG
+    int ablate;            // diagnostics build: bit 0 = output stores to the sink, bit 1 = no prefetch loads, bit 2 = no passes
+    long long *stamps;     // diagnostics build: [wave][group][4] cycle stamps of workgroup stamp_wg (nullptr = off)
+    int stamp_wg;
+#endif
+};
+#ifdef WH_DIAG
+#define WH_STAMP(k)                                                                                         \
+    if (a.stamps && bid == a.n_head + 1 + a.stamp_wg && (tid & 63) == 0 && g < 64)                          \
+        a.stamps[((tid >> 6) * 64 + g) * 4 + (k)] = (long long)__builtin_readcyclecounter();
+#else
+#define WH_STAMP(k)
+#endif
+
+// lanes of a hop's share of a wave -> butterflies of a pass: l_sub = bl UL + ul owns, in round (cb, cu), the butterfly of
+// sub-block bl + BL cb at offset ul + UL cu.  With that split every address of a round is the lane's base plus a
+// compile-time constant (an instruction offset), instead of a division chain per butterfly.
+struct PassMap { bool ok; int UL, BL, CU, CB; };
+constexpr PassMap pass_map(int LS, int nblk, int m) {
+    for (int ul = (m < LS ? m : LS); ul >= 1; --ul)
+        if (m % ul == 0 && LS % ul == 0 && nblk % (LS / ul) == 0) return PassMap{true, ul, LS / ul, m / ul, nblk / (LS / ul)};
+    return PassMap{false, 1, 1, 1, 1};
+}
+
+// Shape of one instance: M channels, T taps per arm, R runs per workgroup, GH hops per group, NWF waves running the
+// passes (0 = all threads, workgroup barriers between passes), WPE waves per SIMD the registers are held to; image
+// layout: word p of a hop image sits at p + (p / PB) PADN (PB = 0: unpadded) and images are IMGS = ph(M) + IMGX words
+// apart -- chosen per M so that the pass reads / writes spread over the LDS banks; TREG of the quad's 4 T taps stay in
+// registers, the rest is re-read from LDS every group.
+template <int M_, int T_, int R_, int GH_, int NWF_, int WPE_, int PB_, int PADN_, int IMGX_, int TREG_>
+struct MidCfg {
+    static constexpr int M = M_, T = T_, R = R_, GH = GH_, NWF = NWF_, WPE = WPE_, PB = PB_, PADN = PADN_, TREG = TREG_;
+    static constexpr int Q = M / 4, HB = M / 2, NT = R * Q, NW = (NT + 63) / 64, NIMG = R * GH;
+    static constexpr int NTL = NW * 64;               // launched threads (threads >= NT own no quad; they join the passes)
+    static constexpr bool WAVE_MODE = NWF > 0;
+    static constexpr int HPW = WAVE_MODE ? NIMG / NWF : NIMG;
+    // workgroup-wide passes: TH threads cooperate on all NIMG images, then every wave does the last pass of HPL images
+    static constexpr int TH = WAVE_MODE ? 64 : (NT / NIMG) * NIMG;   // the quad threads, rounded to whole lanes per hop
+    static constexpr int HPL = WAVE_MODE ? HPW : NIMG / NW;
+    static constexpr MidPlan P = mid_plan(Q);
+    static constexpr int ph(int p) { return PB_ ? p + (p / PB_) * PADN_ : p; }
+    static constexpr int IMGS = ph(M_) + IMGX_;
+    static constexpr int NL4 = (4 * T - TREG + 3) / 4;   // float4 of LDS taps per quad
+    // the images a wave transforms are written by that wave alone: no workgroup barrier at all
+    static constexpr bool SELF = WAVE_MODE && NWF == NW && HPW % GH == 0 && (HPW / GH) * Q == 64;
+    // lanes per hop in the affine forms (0: none)
+    static constexpr int LS = WAVE_MODE ? (64 % HPW == 0 ? 64 / HPW : 0) : TH / NIMG;
+
+    static_assert(P.ok, "M/4 must factor into 2, 3, 5");
+    static_assert(NT <= 1024, "workgroup too large");
+    static_assert(!WAVE_MODE || (NIMG % NWF == 0 && NWF <= NW), "wave mode: whole hop images per wave");
+    static_assert(WAVE_MODE || NIMG % NW == 0, "workgroup mode: the last pass gives every wave whole hop images");
+    static_assert(PB == 0 || Q % PB == 0, "pad blocks must tile a quarter image");
+    static_assert(TREG % 4 == 0 && TREG <= 4 * T, "register taps: whole float4 groups");
+
+    static constexpr bool pass_affine(int pi) {
+        if (LS == 0) return false;
+        const int r = P.r[pi], L = P.L[pi], m = L / r;
+        const PassMap pm = pass_map(LS, M / L, m);
+        if (!pm.ok) return false;
+        for (int ls = 0; ls < LS; ++ls) {
+            const int bl = ls / pm.UL, ul = ls % pm.UL;
+            for (int cb = 0; cb < pm.CB; ++cb)
+                for (int cu = 0; cu < pm.CU; ++cu)
+                    for (int j = 0; j < r; ++j)
+                        if (ph((bl + pm.BL * cb) * L + ul + pm.UL * cu + j * m) !=
+                            ph(bl * L + ul) + ph(pm.BL * cb * L + pm.UL * cu) + ph(j * m))
+                            return false;
+        }
+        return true;
+    }
+    // digit reversal: output index kb = d1 + 4 (d2 + r_0 (d3 + ...)) of the last pass sits at d1 Q + d2 m_0 + d3 m_1 + ...
+    static constexpr int pos_of(int kb) {
+        int rem = kb >> 2, pos = (kb & 3) * Q;
+        for (int p = 0; p < P.np - 1; ++p) {
+            const int rp = P.r[p], mp = P.L[p] / P.r[p];
+            pos += (rem % rp) * mp;
+            rem /= rp;
+        }
+        return pos;
+    }
+    static constexpr int RL = P.r[P.np - 1];       // last radix
+    static constexpr int BPL = M / RL;             // butterflies of the last pass per image
+    static constexpr int LSL = BPL < 64 ? BPL : 64;   // lanes per hop in the last pass
+    static constexpr bool last_affine() {
+        if (64 % LSL != 0 || BPL % LSL != 0 || HPL % (64 / LSL) != 0) return false;
+        for (int kl = 0; kl < LSL; ++kl)
+            for (int c = 0; c < BPL / LSL; ++c)
+                for (int j = 0; j < RL; ++j)
+                    if (ph(pos_of(kl + LSL * c) + j) != ph(pos_of(kl)) + ph(pos_of(LSL * c)) + j) return false;
+        return true;
+    }
 };
 
-// passes PI .. np-2 of the sub-transforms of NI hop images, in place; TH threads cooperate (lt = index among them)
-template <int M, int PI, int TH, int NI, bool WG>
-__device__ __forceinline__ void mid_passes(float2 *im, const float2 *twp, int lt) {
-    constexpr MidPlan P = mid_plan(M / 4);
+// ---- passes, generic form: butterflies flattened over TH cooperating threads (any shape; index arithmetic per butterfly)
+template <class C, int PI, int TH, int NI, bool WG>
+__device__ __forceinline__ void mid_passes_generic(v2f *im, const v4f *twp, int lt) {
+    constexpr MidPlan P = C::P;
     if constexpr (PI < P.np - 1) {
         constexpr int r = P.r[PI], L = P.L[PI], m = L / r;
-        constexpr int BPI = M / r;              // butterflies per image
+        constexpr int BPI = C::M / r;           // butterflies per image
         constexpr int NB = NI * BPI;
         constexpr int ROUNDS = (NB + TH - 1) / TH;
         constexpr int TWO = P.two[PI];
@@ -147,32 +266,28 @@ __device__ __forceinline__ void mid_passes(float2 *im, const float2 *twp, int lt
             if ((c + 1) * TH <= NB || b < NB) {
                 const int s = b / BPI, bb = b - s * BPI;
                 const int blk = bb / m, up = bb - blk * m;
-                float2 *p = im + s * M + blk * L + up;
-                const float2 *tq = twp + TWO + up;
-                float2 v[r];
+                v2f *p = im + s * C::IMGS;
+                const int a0 = blk * L + up;
+                const v4f *tq = twp + TWO + up;
+                v2f v[r];
 #pragma unroll
-                for (int j = 0; j < r; ++j) v[j] = p[j * m];
+                for (int j = 0; j < r; ++j) v[j] = p[C::ph(a0 + j * m)];
                 bfly(v);
-                p[0] = v[0];
+                p[C::ph(a0)] = v[0];
 #pragma unroll
-                for (int k = 1; k < r; ++k) p[k * m] = cmul(v[k], tq[(k - 1) * m]);
+                for (int k = 1; k < r; ++k) p[C::ph(a0 + k * m)] = cmul2(v[k], tq[(k - 1) * m]);
             }
         }
         if (WG) __syncthreads();
         else __builtin_amdgcn_wave_barrier();
-        mid_passes<M, PI + 1, TH, NI, WG>(im, twp, lt);
+        mid_passes_generic<C, PI + 1, TH, NI, WG>(im, twp, lt);
     }
 }
 
-// last pass: image words -> channel outputs in HBM.  Image s of the NI belongs to hop hop0 + (s0 + s) / GH * stride_r +
-// (s0 + s) % GH (s0 = index of im's first image in the workgroup), stored when < limit.
-template <int M, int GH, int TH, int NI>
-__device__ __forceinline__ void mid_last(const float2 *im, float2 *out, int lt, int s0, long long hop0, int stride_r,
-                                         long long limit) {
-    constexpr MidPlan P = mid_plan(M / 4);
-    constexpr int Q = M / 4;
-    constexpr int r = P.r[P.np - 1];
-    constexpr int BPI = M / r;
+template <class C, int TH, int NI>
+__device__ __forceinline__ void mid_last_generic(const v2f *im, v2f *out, v2f *sink, int lt, int s0, long long hop0,
+                                                 int stride_r, long long limit) {
+    constexpr int r = C::RL, BPI = C::BPL;
     constexpr int NB = NI * BPI;
     constexpr int ROUNDS = (NB + TH - 1) / TH;
 #pragma unroll
@@ -180,73 +295,190 @@ __device__ __forceinline__ void mid_last(const float2 *im, float2 *out, int lt, 
         const int b = lt + TH * c;
         if ((c + 1) * TH <= NB || b < NB) {
             const int s = b / BPI, kb = b - s * BPI;
-            // digit reversal: kb = d1 + 4 (d2 + r_0 (d3 + ...)) sits at d1 Q + d2 m_0 + d3 m_1 + ...
-            int rem = kb >> 2, pos = (kb & 3) * Q;
+            const int pos = C::pos_of(kb);
+            const v2f *q = im + s * C::IMGS;
+            v2f v[r];
 #pragma unroll
-            for (int p = 0; p < P.np - 1; ++p) {
-                const int rp = P.r[p], mp = P.L[p] / P.r[p];
-                const int nx = rem / rp;
-                pos += (rem - nx * rp) * mp;
-                rem = nx;
-            }
-            const float2 *q = im + s * M + pos;
-            float2 v[r];
-#pragma unroll
-            for (int j = 0; j < r; ++j) v[j] = q[j];
+            for (int j = 0; j < r; ++j) v[j] = q[C::ph(pos + j)];
             bfly(v);
             const int sg = s0 + s;
-            const long long hop = hop0 + (long long)(sg / GH) * stride_r + (sg % GH);
-            if (hop < limit) {
-                float2 *o = out + (size_t)hop * M + kb;
+            const long long hop = hop0 + (long long)(sg / C::GH) * stride_r + (sg % C::GH);
+            v2f *o = (hop < limit ? out + (size_t)hop * C::M : sink) + kb;
 #pragma unroll
-                for (int k = 0; k < r; ++k) o[k * BPI] = v[k];
+            for (int k = 0; k < r; ++k) o[k * BPI] = v[k];
+        }
+    }
+}
+
+// ---- passes with affine addressing: TH threads (a wave, or the workgroup's first TH threads) on NI images, LS = TH / NI
+// lanes per hop
+template <class C, int PI, int TH, int NI, bool WG>
+__device__ __forceinline__ void mid_passes_affine(v2f *im, const v4f *twp, int lt) {
+    constexpr MidPlan P = C::P;
+    if constexpr (PI < P.np - 1) {
+        if constexpr (C::pass_affine(PI)) {
+            constexpr int r = P.r[PI], L = P.L[PI], m = L / r, LS = C::LS;
+            static_assert(LS * NI == TH, "lanes per hop");
+            constexpr PassMap pm = pass_map(LS, C::M / L, m);
+            if (!WG || lt < TH) {
+                const int hopl = lt / LS, ls = lt - hopl * LS;
+                const int bl = ls / pm.UL, ul = ls - bl * pm.UL;
+                v2f *base = im + hopl * C::IMGS + C::ph(bl * L + ul);
+                const v4f *tq = twp + P.two[PI] + ul;
+#pragma unroll
+                for (int cb = 0; cb < pm.CB; ++cb)
+#pragma unroll
+                    for (int cu = 0; cu < pm.CU; ++cu) {
+                        const int off = C::ph(pm.BL * cb * L + pm.UL * cu);
+                        v2f v[r];
+#pragma unroll
+                        for (int j = 0; j < r; ++j) v[j] = base[off + C::ph(j * m)];
+                        bfly(v);
+                        base[off] = v[0];
+#pragma unroll
+                        for (int k = 1; k < r; ++k) base[off + C::ph(k * m)] = cmul2(v[k], tq[(k - 1) * m + pm.UL * cu]);
+                    }
+            }
+            if (WG) __syncthreads();
+            else __builtin_amdgcn_wave_barrier();
+            mid_passes_affine<C, PI + 1, TH, NI, WG>(im, twp, lt);
+        } else {
+            // this pass (and, for simplicity, the later ones) in the flattened form
+            mid_passes_generic<C, PI, TH, NI, WG>(im, twp, lt);
+        }
+    }
+}
+
+// last pass of a wave's HPL images (lane <-> output index: every store instruction writes consecutive channels)
+template <class C>
+__device__ __forceinline__ void mid_last_wave(const v2f *imw, v2f *out, v2f *sink, int lane, int s0, long long hop0,
+                                              int stride_r, long long limit) {
+    if constexpr (C::last_affine()) {
+        constexpr int r = C::RL, BPL = C::BPL, LSL = C::LSL, HR = 64 / LSL, KC = BPL / LSL;
+        const int hs = HR == 1 ? 0 : lane / LSL, kl = lane - hs * LSL;   // HR == 1: a round is one hop, wave-uniform
+        const v2f *base = imw + hs * C::IMGS + C::ph(C::pos_of(kl));
+#pragma unroll
+        for (int sg = 0; sg < C::HPL / HR; ++sg) {
+            const int s = s0 + sg * HR + hs;                       // image index in the workgroup (wave-uniform if HR == 1)
+            const long long hop = hop0 + (long long)(s / C::GH) * stride_r + (s % C::GH);
+            v2f *orow = (hop < limit ? out + (size_t)hop * C::M : sink) + kl;
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                const int off = sg * HR * C::IMGS + C::ph(C::pos_of(LSL * c));
+                v2f v[r];
+#pragma unroll
+                for (int j = 0; j < r; ++j) v[j] = base[off + j];
+                bfly(v);
+#pragma unroll
+                for (int k = 0; k < r; ++k) orow[LSL * c + k * BPL] = v[k];
             }
         }
+    } else {
+        mid_last_generic<C, 64, C::HPL>(imw, out, sink, lane, s0, hop0, stride_r, limit);
     }
 }
 
-
-// the passes of the workgroup's hop images + their stores (wave mode: wave w owns images [w HPW, (w+1) HPW))
-template <int M, int GH, int NT, int NIMG, int NWF>
-__device__ __forceinline__ void mid_transform(float2 *img, const float2 *twp, float2 *out, int tid, long long hop_g,
-                                              int stride_r, long long limit) {
-    constexpr bool WAVE_MODE = NWF > 0;
-    constexpr int HPW = WAVE_MODE ? NIMG / NWF : NIMG;
+// the passes of the hop images + their stores.  Wave mode: wave w < NWF owns images [w HPW, (w+1) HPW), no workgroup
+// barrier inside.  Workgroup mode: every thread takes part in every pass (barriers between them), then wave w does the
+// last pass of images [w HPL, (w+1) HPL).  Every wave of the workgroup must call this in workgroup mode.
+template <class C>
+__device__ __forceinline__ void mid_transform(v2f *img, const v4f *twp, v2f *out, v2f *sink, int tid, int wave,
+                                              long long hop_g, int stride_r, long long limit) {
     // opaque copy of the thread index: the image / twiddle / output offsets of the passes are loop invariant and would
     // otherwise be hoisted out of the group loop and parked in registers for the whole run
-    int lt = WAVE_MODE ? (tid & 63) : tid;
-    asm volatile("" : "+v"(lt));
-    if (WAVE_MODE) {
-        const int wave = tid >> 6;
-        if (wave < NWF) {
-            float2 *im = img + wave * HPW * M;
-            mid_passes<M, 0, 64, HPW, false>(im, twp, lt);
-            mid_last<M, GH, 64, HPW>(im, out, lt, wave * HPW, hop_g, stride_r, limit);
+    int lt = C::WAVE_MODE ? (tid & 63) : tid;
+    if (C::WPE >= 4 || !C::WAVE_MODE) asm volatile("" : "+v"(lt));   // (with registers to spare the hoisted offsets are cheaper)
+    if constexpr (C::WAVE_MODE) {
+        if (wave < C::NWF) {
+            v2f *im = img + wave * C::HPW * C::IMGS;
+            mid_passes_affine<C, 0, 64, C::HPW, false>(im, twp, lt);
+            mid_last_wave<C>(im, out, sink, lt, wave * C::HPW, hop_g, stride_r, limit);
         }
     } else {
-        mid_passes<M, 0, NT, NIMG, true>(img, twp, lt);
-        mid_last<M, GH, NT, NIMG>(img, out, lt, 0, hop_g, stride_r, limit);
+        mid_passes_affine<C, 0, C::TH, C::NIMG, true>(img, twp, lt);
+        mid_last_wave<C>(img + wave * C::HPL * C::IMGS, out, sink, lt & 63, wave * C::HPL, hop_g, stride_r, limit);
     }
 }
 
-template <int M, int T, int R, int GH, int NWF, int WPE, int FMT>
-__global__ __launch_bounds__(R * (M / 4)) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void pfb_mid_kernel(MidArgs a) {
-    constexpr int Q = M / 4, HB = M / 2, NT = R * Q, NW = (NT + 63) / 64, NIMG = R * GH;
-    constexpr MidPlan P = mid_plan(Q);
-    static_assert(P.ok, "M/4 must factor into 2, 3, 5");
-    static_assert(NT <= 1024, "workgroup too large");
-    constexpr bool WAVE_MODE = NWF > 0;
-    static_assert(!WAVE_MODE || (NIMG % NWF == 0 && NWF <= NW), "wave mode: whole hop images per wave");
-    constexpr int HPW = WAVE_MODE ? NIMG / NWF : NIMG;
-    // the images a wave transforms are written by that wave alone: no workgroup barrier at all
-    constexpr bool SELF = WAVE_MODE && NWF == NW && HPW % GH == 0 && (HPW / GH) * Q == 64;
+// one group of a thread's run: arm MAC + radix-4 stage of GH hops into the images, window slide, next prefetch
+template <class C, int FMT>
+__device__ __forceinline__ void mid_mac_group(const MidArgs &a, v2f (&wA)[C::T + C::GH], v2f (&wB)[C::T + C::GH],
+                                              const v2f (&tpr_in)[C::TREG > 0 ? C::TREG / 2 : 1], const v4f *tapl, v2f *imr,
+                                              v2f tw1, v2f tw2, v2f tw3, int u, long long &h, bool more, bool quad) {
+    constexpr int T = C::T, GH = C::GH, Q = C::Q, HB = C::HB, IMGS = C::IMGS, TREG = C::TREG, NL4 = C::NL4;
+    // the register taps stay PAIRS: without the opaque touch the compiler hoists a broadcast {t, t} copy of every tap
+    // out of the group loop (two registers per tap instead of one)
+    v2f tpr[TREG > 0 ? TREG / 2 : 1];
+#pragma unroll
+    for (int e = 0; e < TREG / 2; ++e) {
+        tpr[e] = tpr_in[e];
+        asm volatile("" : "+v"(tpr[e]));
+    }
+    {
+        // the quad's LDS taps, re-read every group (opaque index: hoisted out of the loop they would be held in
+        // registers through the transform phase; here they are live during the MAC only)
+        int uo = u;
+        asm volatile("" : "+v"(uo));
+        v2f tpl[NL4 > 0 ? 2 * NL4 : 1];
+#pragma unroll
+        for (int k = 0; k < NL4; ++k) {
+            const v4f t4 = tapl[uo * NL4 + k];
+            tpl[2 * k] = __builtin_shufflevector(t4, t4, 0, 1);
+            tpl[2 * k + 1] = __builtin_shufflevector(t4, t4, 2, 3);
+        }
+#define WH_TAPFMA(q, j, w, acc)                                                                         \
+(((q) * T + (j)) < TREG ? pk_fma_bc(((q) * T + (j)) & 1, w, tpr[(((q) * T + (j)) < TREG ? ((q) * T + (j)) : 0) >> 1], acc) \
+                        : pk_fma_bc(((q) * T + (j) - TREG) & 1, w, tpl[(((q) * T + (j)) >= TREG ? ((q) * T + (j) - TREG) : 0) >> 1], acc))
+#pragma unroll
+        for (int i = 0; i < GH; ++i) {
+            // hop h+i: column u uses c_{h+i-j} = w[i + T-1 - j]; column u + HB uses w[i + T - j]
+            v2f y[4] = {v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}};
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+                y[0] = WH_TAPFMA(0, j, wA[i + T - 1 - j], y[0]);
+                y[1] = WH_TAPFMA(1, j, wB[i + T - 1 - j], y[1]);
+                y[2] = WH_TAPFMA(2, j, wA[i + T - j], y[2]);
+                y[3] = WH_TAPFMA(3, j, wB[i + T - j], y[3]);
+            }
+            bfly(y);
+            v2f *L = imr + i * IMGS;
+            L[0] = y[0];
+            L[C::ph(Q)] = cmul3(y[1], tw1);
+            L[C::ph(2 * Q)] = cmul3(y[2], tw2);
+            L[C::ph(3 * Q)] = cmul3(y[3], tw3);
+        }
+#undef WH_TAPFMA
+    }
+    // slide the windows, then load the next group's blocks into the freed tail slots
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+        wA[i] = wA[i + GH];
+        wB[i] = wB[i + GH];
+    }
+    h += GH;
+    if (more) {
+#pragma unroll
+        for (int i = 0; i < GH; ++i) {
+            long long gb = h + 1 + i;
+            if (gb > a.max_block) gb = a.max_block;
+            wA[T + i] = ld_iq<FMT>(a.x, gb * HB + u);
+            wB[T + i] = ld_iq<FMT>(a.x, gb * HB + u + Q);
+        }
+    }
+}
 
-    __shared__ __attribute__((aligned(16))) float2 img[NIMG * M];
-    __shared__ float2 twp[P.twn > 0 ? P.twn : 1];
-    // taps of quad u: 36 floats (e = q T + j) padded to TP4 float4; the 144-byte row stride makes the ds_read_b128 of 16
-    // consecutive lanes cover all 64 banks once
-    constexpr int TP4 = (4 * T + 3) / 4;
-    __shared__ float4 tapl[Q * TP4];
+template <class C, int FMT>
+__global__ __launch_bounds__(C::NTL) __attribute__((amdgpu_waves_per_eu(C::WPE, C::WPE))) void pfb_mid_kernel(MidArgs a) {
+    constexpr int M = C::M, T = C::T, R = C::R, GH = C::GH, Q = C::Q, HB = C::HB, NT = C::NTL, NIMG = C::NIMG;
+    constexpr int IMGS = C::IMGS, TREG = C::TREG, NL4 = C::NL4;
+    constexpr MidPlan P = C::P;
+
+    __shared__ __attribute__((aligned(16))) v2f img[NIMG * IMGS];
+    // per-pass twiddle tables, entries (wx, wy, -wy, wx): a complex product is two packed instructions
+    __shared__ v4f twp[P.twn > 0 ? P.twn : 1];
+    // LDS taps of quad u: the taps e = q T + j >= TREG, NL4 float4 per quad (M = 320, TREG = 8: 7 float4 = 112 bytes per
+    // row, and the ds_read_b128 of 16 consecutive lanes cover all 64 banks once)
+    __shared__ v4f tapl[NL4 > 0 ? Q * NL4 : 1];
 
     const int tid = threadIdx.x;
     const int bid = blockIdx.x;
@@ -255,11 +487,11 @@ __global__ __launch_bounds__(R * (M / 4)) __attribute__((amdgpu_waves_per_eu(WPE
         for (int idx = tid; idx < M * T; idx += NT) {
             const int k = idx / T, j = idx - k * T;
             const long long g = a.H - 1 - j;
-            float2 v;
+            v2f v;
             if (g >= 0) v = ld_iq<FMT>(a.x, g * HB + k);
             else {
                 const int col = (int)(-g - 1);
-                v = col < T ? a.hist[(size_t)k * T + col] : make_float2(0.f, 0.f);
+                v = col < T ? a.hist[(size_t)k * T + col] : v2f{0.f, 0.f};
             }
             a.new_hist[idx] = v;
         }
@@ -272,11 +504,14 @@ __global__ __launch_bounds__(R * (M / 4)) __attribute__((amdgpu_waves_per_eu(WPE
         const int rp = P.r[p], Lp = P.L[p], mp = Lp / rp;
         for (int e = tid; e < (rp - 1) * mp; e += NT) {
             const int k = e / mp + 1, up = e - (k - 1) * mp;
-            twp[P.two[p] + e] = a.tw[(up * k * (M / Lp)) % M];
+            const float2 w = a.tw[(up * k * (M / Lp)) % M];
+            twp[P.two[p] + e] = v4f{w.x, w.y, -w.y, w.x};
         }
     }
 
-    const int r = tid / Q, u = tid - r * Q;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool quad = tid < C::NT;                       // this thread owns a quad of a run
+    const int r = quad ? tid / Q : R - 1, u = quad ? tid - r * Q : Q - 1;   // (the others mirror the last quad, nothing written)
 
     if (bid < a.n_head) {
         // head hops: every column from the carried history / the stream, j ascending like the packed MAC below
@@ -287,15 +522,15 @@ __global__ __launch_bounds__(R * (M / 4)) __attribute__((amdgpu_waves_per_eu(WPE
             const int s = j0 / Q, uu = j0 - s * Q;
             const long long hop = hop_base + s;
             if (hop >= limit) continue;
-            float2 z[4];
+            v2f z[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int k = uu + q * Q;
-                float re = 0.f, im = 0.f;
+                v2f acc = v2f{0.f, 0.f};
 #pragma nounroll
                 for (int j = 0; j < T; ++j) {
                     const long long gb = hop - j;
-                    float2 c;
+                    v2f c;
                     if (gb >= 0) {
                         long long idx = gb * HB + k;
                         if (idx >= a.n) idx = a.n - 1;
@@ -303,21 +538,20 @@ __global__ __launch_bounds__(R * (M / 4)) __attribute__((amdgpu_waves_per_eu(WPE
                     } else {
                         c = a.hist[(size_t)k * T + (int)(-gb - 1)];
                     }
-                    const float w = a.arms[(size_t)k * T + j];
-                    re = fmaf(c.x, w, re);
-                    im = fmaf(c.y, w, im);
+                    acc = WH_FMA(c, bc(a.arms[(size_t)k * T + j]), acc);
                 }
-                z[q] = make_float2(re, im);
+                z[q] = acc;
             }
-            fft4(z[0], z[1], z[2], z[3]);
-            float2 *L = img + s * M + uu;
+            bfly(z);
+            const float2 w1 = a.tw[uu], w2 = a.tw[2 * uu], w3 = a.tw[3 * uu];
+            v2f *L = img + s * IMGS + C::ph(uu);
             L[0] = z[0];
-            L[Q] = cmul(z[1], a.tw[uu]);
-            L[2 * Q] = cmul(z[2], a.tw[2 * uu]);
-            L[3 * Q] = cmul(z[3], a.tw[3 * uu]);
+            L[C::ph(Q)] = cmul3(z[1], v2f{w1.x, w1.y});
+            L[C::ph(2 * Q)] = cmul3(z[2], v2f{w2.x, w2.y});
+            L[C::ph(3 * Q)] = cmul3(z[3], v2f{w3.x, w3.y});
         }
         __syncthreads();   // images and twiddle tables
-        mid_transform<M, GH, NT, NIMG, NWF>(img, twp, a.out, tid, hop_base, GH, limit);
+        mid_transform<C>(img, twp, a.out, a.sink, tid, wave, hop_base, GH, limit);
         return;
     }
 
@@ -325,11 +559,25 @@ __global__ __launch_bounds__(R * (M / 4)) __attribute__((amdgpu_waves_per_eu(WPE
     const int ngroups = a.hpr / GH;
 
     // stage-1 twiddles W_M^(u k1)
-    const float2 tw1 = a.tw[u], tw2 = a.tw[2 * u], tw3 = a.tw[3 * u];
-    for (int e = tid; e < Q * TP4 * 4; e += NT) {
-        const int uu = e / (TP4 * 4), f = e - uu * (TP4 * 4);   // f = q T + j
-        const int q = f / T, j = f - q * T;
-        reinterpret_cast<float *>(tapl)[e] = f < 4 * T ? a.arms[(size_t)(uu + q * Q) * T + j] : 0.f;
+    v2f tw1, tw2, tw3;
+    {
+        const float2 w1 = a.tw[u], w2 = a.tw[2 * u], w3 = a.tw[3 * u];
+        tw1 = v2f{w1.x, w1.y}; tw2 = v2f{w2.x, w2.y}; tw3 = v2f{w3.x, w3.y};
+    }
+    // taps e = q T + j: the first TREG in registers (pairs), the rest in LDS
+    v2f tpr[TREG > 0 ? TREG / 2 : 1];
+#pragma unroll
+    for (int e = 0; e < TREG; e += 2) {
+        const int q0 = e / T, j0 = e - q0 * T, q1 = (e + 1) / T, j1 = (e + 1) - q1 * T;
+        tpr[e / 2] = v2f{a.arms[(size_t)(u + q0 * Q) * T + j0], a.arms[(size_t)(u + q1 * Q) * T + j1]};
+        asm volatile("" : "+v"(tpr[e / 2]));   // a PAIR from here on: seen through, each tap gets a {t, t} register pair
+    }
+    if constexpr (NL4 > 0) {
+        for (int e = tid; e < Q * NL4 * 4; e += NT) {
+            const int uu = e / (NL4 * 4), f = TREG + e - uu * (NL4 * 4);   // f = q T + j
+            const int q = f / T, j = f - q * T;
+            reinterpret_cast<float *>(tapl)[e] = f < 4 * T ? a.arms[(size_t)(uu + q * Q) * T + j] : 0.f;
+        }
     }
     // wA[i] = x[(h - (T-1) + i) HB + u], wB[i] = ... + Q; slots T.. hold the group's new blocks
     v2f wA[T + GH], wB[T + GH];
@@ -338,117 +586,101 @@ __global__ __launch_bounds__(R * (M / 4)) __attribute__((amdgpu_waves_per_eu(WPE
     for (int i = 0; i < T + GH; ++i) {
         long long g = h - (T - 1) + i;
         if (g > a.max_block) g = a.max_block;
-        const float2 va = ld_iq<FMT>(a.x, g * HB + u), vb = ld_iq<FMT>(a.x, g * HB + u + Q);
-        wA[i] = v2f{va.x, va.y};
-        wB[i] = v2f{vb.x, vb.y};
+        wA[i] = ld_iq<FMT>(a.x, g * HB + u);
+        wB[i] = ld_iq<FMT>(a.x, g * HB + u + Q);
     }
+    v2f *const imr = img + r * GH * IMGS + C::ph(u);   // this thread's word of its run's first image
     __syncthreads();   // twiddle and tap tables
 
+#ifdef WH_DIAG
+#define WH_MORE(g) ((g) + 1 < ngroups && !(a.ablate & 2))
+#else
+#define WH_MORE(g) ((g) + 1 < ngroups)
+#endif
+#ifdef WH_DIAG
+    const long long limit = (a.ablate & 1) ? 0 : a.H;   // bit 0: every output store goes to the sink row
+    const bool passes = !(a.ablate & 4);
+#else
+    const long long limit = a.H;
+    constexpr bool passes = true;
+#endif
     for (int g = 0; g < ngroups; ++g) {
         const long long hop_g = hop_base + (long long)g * GH;
         if (hop_g >= a.H) break;   // uniform: this and every later group of the workgroup is past the end
-        {
-            // the quad's taps, re-read every group (opaque index: hoisted out of the loop they would hold 36 registers
-            // through the transform phase; here they are live during the MAC only)
-            int uo = u;
-            asm volatile("" : "+v"(uo));
-            v2f tp[2 * TP4];
-#pragma unroll
-            for (int k = 0; k < TP4; ++k) {
-                const float4 t4 = tapl[uo * TP4 + k];
-                tp[2 * k] = v2f{t4.x, t4.y};
-                tp[2 * k + 1] = v2f{t4.z, t4.w};
-            }
-#define WH_TAPFMA(q, j, w, acc) pk_fma_bc(((q) * T + (j)) & 1, w, tp[((q) * T + (j)) >> 1], acc)
-#pragma unroll
-            for (int i = 0; i < GH; ++i) {
-                // hop h+i: column u uses c_{h+i-j} = w[i + T-1 - j]; column u + HB uses w[i + T - j]
-                v2f y0 = v2f{0.f, 0.f}, y1 = y0, y2 = y0, y3 = y0;
-#pragma unroll
-                for (int j = 0; j < T; ++j) {
-                    y0 = WH_TAPFMA(0, j, wA[i + T - 1 - j], y0);
-                    y1 = WH_TAPFMA(1, j, wB[i + T - 1 - j], y1);
-                    y2 = WH_TAPFMA(2, j, wA[i + T - j], y2);
-                    y3 = WH_TAPFMA(3, j, wB[i + T - j], y3);
-                }
-                float2 z0 = make_float2(y0.x, y0.y), z1 = make_float2(y1.x, y1.y);
-                float2 z2 = make_float2(y2.x, y2.y), z3 = make_float2(y3.x, y3.y);
-                fft4(z0, z1, z2, z3);
-                float2 *L = img + (r * GH + i) * M + u;
-                L[0] = z0;
-                L[Q] = cmul(z1, tw1);
-                L[2 * Q] = cmul(z2, tw2);
-                L[3 * Q] = cmul(z3, tw3);
-            }
-#undef WH_TAPFMA
-        }
-        // slide the windows, then load the next group's blocks into the freed tail slots
-#pragma unroll
-        for (int i = 0; i < T; ++i) {
-            wA[i] = wA[i + GH];
-            wB[i] = wB[i + GH];
-        }
-        h += GH;
-        if (g + 1 < ngroups) {
-#pragma unroll
-            for (int i = 0; i < GH; ++i) {
-                long long gb = h + 1 + i;
-                if (gb > a.max_block) gb = a.max_block;
-                const float2 va = ld_iq<FMT>(a.x, gb * HB + u), vb = ld_iq<FMT>(a.x, gb * HB + u + Q);
-                wA[T + i] = v2f{va.x, va.y};
-                wB[T + i] = v2f{vb.x, vb.y};
-            }
-        }
-        if (SELF) __builtin_amdgcn_wave_barrier();
+        WH_STAMP(0)
+        mid_mac_group<C, FMT>(a, wA, wB, tpr, tapl, imr, tw1, tw2, tw3, u, h, WH_MORE(g), quad);
+        WH_STAMP(1)
+        if (C::SELF) __builtin_amdgcn_wave_barrier();
         else __syncthreads();
-        mid_transform<M, GH, NT, NIMG, NWF>(img, twp, a.out, tid, hop_g, a.hpr, a.H);
-        if (SELF) __builtin_amdgcn_wave_barrier();
+        WH_STAMP(2)
+        if (passes) mid_transform<C>(img, twp, a.out, a.sink, tid, wave, hop_g, a.hpr, limit);
+        WH_STAMP(3)
+        if (C::SELF) __builtin_amdgcn_wave_barrier();
         else __syncthreads();
     }
 }
 
+#ifdef WH_DIAG
+long long *g_diag_stamps = nullptr;
+int g_diag_stamp_wg = 0;
+#endif
+
 // ---- host side -------------------------------------------------------------------------------------------------
 
-// (M, R runs per workgroup, GH hops per group, NWF waves running the passes; 0 = all threads with workgroup barriers,
-//  WPE waves per SIMD the register allocation is held to)
+// (M, R, GH, NWF, WPE, PB, PADN, IMGX, TREG): see MidCfg
+#ifndef WH_MID_320
+#define WH_MID_320 3, 4, 0, 3, 20, 1, 0, 36
+#endif
+#define WH_MID_X(X, ...) X(__VA_ARGS__)
 #define WH_MID_CONFIGS(X) \
-    X(320, 4, 4, 4, 4)
+    WH_MID_X(X, 320, WH_MID_320)
 
-template <int M, int T, int R, int GH, int NWF, int WPE>
+template <class C>
 int mid_launch_t(const PfbMidCall &c, hipStream_t st) {
-    constexpr int NT = R * (M / 4), NIMG = R * GH;
-    static int wg_per_cu[2] = {0, 0};   // occupancy of the two format instances (same for every device of the node)
+    constexpr int M = C::M, T = C::T, R = C::R, GH = C::GH, NT = C::NTL, NIMG = C::NIMG;
+    static int wg_per_cu[2] = {0, 0};   // resident workgroups per CU of the two format instances
     const int f = c.fmt == 1 ? 1 : 0;
-    auto kern = f ? pfb_mid_kernel<M, T, R, GH, NWF, WPE, 1> : pfb_mid_kernel<M, T, R, GH, NWF, WPE, 0>;
+    auto kern = f ? pfb_mid_kernel<C, 1> : pfb_mid_kernel<C, 0>;
     if (wg_per_cu[f] == 0) {
-        int nb = 0;
-        WH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, NT, 0));
+        // by registers: the kernel is compiled for WPE waves per SIMD (4 SIMDs per CU); by LDS: 160 KiB per CU
+        hipFuncAttributes fa;
+        WH_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern)));
+        const int by_waves = 4 * C::WPE / (NT / 64);
+        const int by_lds = (int)((160 * 1024) / (((size_t)fa.sharedSizeBytes + 511) / 512 * 512));
+        const int nb = by_waves < by_lds ? by_waves : by_lds;
         wg_per_cu[f] = nb > 0 ? nb : 1;
     }
     MidArgs a;
-    a.x = c.x; a.hist = c.hist; a.new_hist = c.new_hist; a.out = c.out; a.arms = c.arms; a.tw = c.tw;
+    a.x = c.x; a.arms = c.arms; a.tw = c.tw;
+    a.hist = reinterpret_cast<const v2f *>(c.hist); a.new_hist = reinterpret_cast<v2f *>(c.new_hist);
+    a.out = reinterpret_cast<v2f *>(c.out); a.sink = reinterpret_cast<v2f *>(c.sink);
     a.H = c.H; a.n = (long long)c.n;
     a.max_block = (long long)(c.n / (size_t)(M / 2)) - 1;
     const long long nh = c.H - (T - 1);   // hops of the runs
     int hpr = GH;
     long long n_main = 0;
     if (nh > 0) {
-        // every workgroup resident at once when the input allows (a second, nearly empty round of workgroups would
-        // double the time of a small call), runs of at most 128 hops (halo 9 / 128), at least 16 (halo 9 / 16)
+        // Run length: the launch takes rounds(hpr) x (hpr + fixed cost of a run, about 12 hops: window fill, tables), with
+        // rounds = workgroups / resident slots rounded UP -- a nearly empty last round costs as much as a full one, so
+        // small calls get every workgroup resident at once.  16..128 hops (halo 9 / hpr of the reads).
         const long long slots = (long long)c.cu_count * wg_per_cu[f];
-        long long v = 0;
-        for (long long k = 1; k <= 4096; ++k) {
-            v = (nh + R * slots * k - 1) / (R * slots * k);
-            v = (v + GH - 1) / GH * GH;
-            if (v <= 128) break;
+        long long v = 16, best = -1;
+        for (long long cand = (16 + GH - 1) / GH * GH; cand <= 128; cand += GH) {
+            const long long wgs = ((nh + cand - 1) / cand + R - 1) / R;
+            const long long cost = ((wgs + slots - 1) / slots) * (cand + 12);
+            if (best < 0 || cost <= best) { best = cost; v = cand; }
         }
-        if (v < 16) v = (16 + GH - 1) / GH * GH;
         if (c.hops_per_run > 0) v = (c.hops_per_run + GH - 1) / GH * GH;
         hpr = (int)v;
         const long long runs = (nh + hpr - 1) / hpr;
         n_main = (runs + R - 1) / R;
     }
     a.hpr = hpr;
+#ifdef WH_DIAG
+    a.ablate = c.stats_only >> 8;   // diagnostics build: wh_pfb_tune(key 4) rides in the upper bits
+    a.stamps = g_diag_stamps;
+    a.stamp_wg = g_diag_stamp_wg;
+#endif
     const long long head_hops = c.H < T - 1 ? c.H : T - 1;
     a.n_head = (int)((head_hops + NIMG - 1) / NIMG);
     const long long grid = a.n_head + 1 + n_main;
@@ -460,11 +692,15 @@ int mid_launch_t(const PfbMidCall &c, hipStream_t st) {
 
 }  // namespace
 
+#ifdef WH_DIAG
+extern "C" void wh_diag_mid_stamps(long long *d_buf, int wg) { g_diag_stamps = d_buf; g_diag_stamp_wg = wg; }
+#endif
+
 namespace wh {
 
 bool pfb_mid_supported(int M, int T) {
     if (T != 9) return false;
-#define X(M_, R_, GH_, NWF_, WPE_) if (M == M_) return true;
+#define X(M_, R_, GH_, NWF_, WPE_, PB_, PADN_, IMGX_, TREG_) if (M == M_) return true;
     WH_MID_CONFIGS(X)
 #undef X
     return false;
@@ -472,7 +708,8 @@ bool pfb_mid_supported(int M, int T) {
 
 int pfb_mid_launch(int M, int T, const PfbMidCall &c, hipStream_t st) {
     if (T == 9) {
-#define X(M_, R_, GH_, NWF_, WPE_) if (M == M_) return mid_launch_t<M_, 9, R_, GH_, NWF_, WPE_>(c, st);
+#define X(M_, R_, GH_, NWF_, WPE_, PB_, PADN_, IMGX_, TREG_) \
+    if (M == M_) return mid_launch_t<MidCfg<M_, 9, R_, GH_, NWF_, WPE_, PB_, PADN_, IMGX_, TREG_>>(c, st);
         WH_MID_CONFIGS(X)
 #undef X
     }
