@@ -1,14 +1,15 @@
 #!/usr/bin/env python3
-"""Shaped filterbank kernels (pfb_mid.hip) against the run kernel and the per-hop kernel: agreement and time per call,
-with a sweep of the run length.  Diagnostics only."""
+"""Shaped filterbank kernels (pfb_mid.hip) against the kernel each channel count took before (run kernel for 4 | M <= 512,
+per-hop kernel otherwise): time per call and algorithmic TB/s (24 B per input sample).  `--sweep` adds the run-length
+sweep for the first shape.  pfb_mid_bench.py [--sweep] [M ...]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "wavecap-sdr_amd")]
 import torch, wavehip
 
-CASES = [(8_000_000, 25_000)]
-if len(sys.argv) > 1:
-    CASES = [tuple(int(v) for v in a.split(":")) for a in sys.argv[1:]]
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+sweep = "--sweep" in sys.argv
+MS = [int(a) for a in args] or [320]
 
 
 def timeit(ch, x, out, reps=10):
@@ -19,27 +20,30 @@ def timeit(ch, x, out, reps=10):
     return (time.perf_counter() - t0) / reps
 
 
-for fs, bw in CASES:
+for M in MS:
+    fs, bw = M * 25_000, 25_000
     sh = wavehip.PolyphaseChannelizer(fs, bw)
-    M = sh.channel_count
-    hop = wavehip.PolyphaseChannelizer(fs, bw).tune(path="per_hop")
+    assert sh.channel_count == M
     g = torch.Generator(device="cuda").manual_seed(M)
-    x = torch.view_as_complex(torch.randn(M * 1000 + 17, 2, device="cuda", generator=g).mul_(0.5))
-    ya, yb = sh.process_device(x), hop.process_device(x)
-    err = ((ya - yb).abs().max() / yb.abs().max()).item()
-    print(f"M={M}: shaped vs per-hop kernel peak-relative difference {err:.2e}", flush=True)
     for logn in (24, 26):
         n = 1 << logn
         x = torch.view_as_complex(torch.randn(n, 2, device="cuda", generator=g).mul_(0.5))
         out = torch.empty((sh.hops(n), M), dtype=torch.complex64, device="cuda")
-        line = [f"auto:{timeit(sh, x, out)*1e6:7.1f}"]
-        for hpr in (16, 24, 32, 48, 64, 96, 128):
-            sh.tune(hops_per_run=hpr)
-            line.append(f"{hpr}:{timeit(sh, x, out)*1e6:7.1f}")
-        sh.tune(hops_per_run=0)
+        t = timeit(sh, x, out)
+        line = f"M={M:5d} n=2^{logn}: shaped {t*1e6:8.1f} us = {n*24/t/1e12:5.2f} TB/s"
         try:
-            run = wavehip.PolyphaseChannelizer(fs, bw).tune(path="run")
-            line.append(f"run-kernel:{timeit(run, x, out)*1e6:7.1f}")
+            old = wavehip.PolyphaseChannelizer(fs, bw).tune(path="run")
+            name = "run kernel"
         except RuntimeError:
-            pass
-        print(f"M={M} n=2^{logn} (floor {n*24/5e12*1e6:6.1f} us @5TB/s) us per call by hops/run  " + "  ".join(line), flush=True)
+            old = wavehip.PolyphaseChannelizer(fs, bw).tune(path="per_hop")
+            name = "per-hop kernel"
+        to = timeit(old, x, out, reps=3)
+        line += f"   {name} {to*1e6:9.1f} us   x{to/t:.2f}"
+        if sweep and M == MS[0]:
+            sw = []
+            for hpr in (16, 24, 32, 48, 64, 96, 128):
+                sh.tune(hops_per_run=hpr)
+                sw.append(f"{hpr}:{timeit(sh, x, out)*1e6:7.1f}")
+            sh.tune(hops_per_run=0)
+            line += "   by hops/run " + " ".join(sw)
+        print(line, flush=True)

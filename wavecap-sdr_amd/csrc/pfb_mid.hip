@@ -184,8 +184,8 @@ constexpr PassMap pass_map(int LS, int nblk, int m) {
 // passes (0 = all threads, workgroup barriers between passes), WPE waves per SIMD the registers are held to; image
 // layout: word p of a hop image sits at p + (p / PB) PADN (PB = 0: unpadded) and images are IMGS = ph(M) + IMGX words
 // apart -- chosen per M so that the pass reads / writes spread over the LDS banks; TREG of the quad's 4 T taps stay in
-// registers, the rest is re-read from LDS every group.
-template <int M_, int T_, int R_, int GH_, int NWF_, int WPE_, int PB_, int PADN_, int IMGX_, int TREG_>
+// registers, the rest is re-read from LDS every group; LSP lanes per hop image in the workgroup-wide passes (0 = all).
+template <int M_, int T_, int R_, int GH_, int NWF_, int WPE_, int PB_, int PADN_, int IMGX_, int TREG_, int LSP_>
 struct MidCfg {
     static constexpr int M = M_, T = T_, R = R_, GH = GH_, NWF = NWF_, WPE = WPE_, PB = PB_, PADN = PADN_, TREG = TREG_;
     static constexpr int Q = M / 4, HB = M / 2, NT = R * Q, NW = (NT + 63) / 64, NIMG = R * GH;
@@ -193,8 +193,9 @@ struct MidCfg {
     static constexpr bool WAVE_MODE = NWF > 0;
     static constexpr int HPW = WAVE_MODE ? NIMG / NWF : NIMG;
     // workgroup-wide passes: TH threads cooperate on all NIMG images, then every wave does the last pass of HPL images
-    static constexpr int TH = WAVE_MODE ? 64 : (NT / NIMG) * NIMG;   // the quad threads, rounded to whole lanes per hop
-    static constexpr int HPL = WAVE_MODE ? HPW : NIMG / NW;
+    // LSP_ lanes per hop image (0: as many as the quad threads give); fewer when the pass shapes need a rounder number
+    static constexpr int TH = WAVE_MODE ? 64 : (LSP_ > 0 ? LSP_ : NT / NIMG) * NIMG;
+    static constexpr int HPL = HPW;                   // images of a wave's last pass in wave mode
     static constexpr MidPlan P = mid_plan(Q);
     static constexpr int ph(int p) { return PB_ ? p + (p / PB_) * PADN_ : p; }
     static constexpr int IMGS = ph(M_) + IMGX_;
@@ -207,7 +208,6 @@ struct MidCfg {
     static_assert(P.ok, "M/4 must factor into 2, 3, 5");
     static_assert(NT <= 1024, "workgroup too large");
     static_assert(!WAVE_MODE || (NIMG % NWF == 0 && NWF <= NW), "wave mode: whole hop images per wave");
-    static_assert(WAVE_MODE || NIMG % NW == 0, "workgroup mode: the last pass gives every wave whole hop images");
     static_assert(PB == 0 || Q % PB == 0, "pad blocks must tile a quarter image");
     static_assert(TREG % 4 == 0 && TREG <= 4 * T, "register taps: whole float4 groups");
 
@@ -239,15 +239,25 @@ struct MidCfg {
     }
     static constexpr int RL = P.r[P.np - 1];       // last radix
     static constexpr int BPL = M / RL;             // butterflies of the last pass per image
-    static constexpr int LSL = BPL < 64 ? BPL : 64;   // lanes per hop in the last pass
-    static constexpr bool last_affine() {
-        if (64 % LSL != 0 || BPL % LSL != 0 || HPL % (64 / LSL) != 0) return false;
-        for (int kl = 0; kl < LSL; ++kl)
-            for (int c = 0; c < BPL / LSL; ++c)
+    static constexpr int LSL = BPL < 64 ? BPL : 64;   // wave mode: lanes per hop in the last pass
+    static constexpr bool lsl_affine(int lsl) {
+        for (int kl = 0; kl < lsl; ++kl)
+            for (int c = 0; c < BPL / lsl; ++c)
                 for (int j = 0; j < RL; ++j)
-                    if (ph(pos_of(kl + LSL * c) + j) != ph(pos_of(kl)) + ph(pos_of(LSL * c)) + j) return false;
+                    if (ph(pos_of(kl + lsl * c) + j) != ph(pos_of(kl)) + ph(pos_of(lsl * c)) + j) return false;
         return true;
     }
+    static constexpr bool last_affine() {
+        if (64 % LSL != 0 || BPL % LSL != 0 || HPL % (64 / LSL) != 0) return false;
+        return lsl_affine(LSL);
+    }
+    // workgroup mode: the last pass is cut into units (64 / LSU hops) x (LSU consecutive outputs), NU / NW units per wave
+    static constexpr int pick_lsu() {
+        for (int c = 64; c >= 4; c >>= 1)
+            if (BPL % c == 0 && NIMG % (64 / c) == 0 && ((NIMG / (64 / c)) * (BPL / c)) % NW == 0 && lsl_affine(c)) return c;
+        return 0;
+    }
+    static constexpr int LSU = WAVE_MODE ? 0 : pick_lsu();
 };
 
 // ---- passes, generic form: butterflies flattened over TH cooperating threads (any shape; index arithmetic per butterfly)
@@ -378,6 +388,31 @@ __device__ __forceinline__ void mid_last_wave(const v2f *imw, v2f *out, v2f *sin
     }
 }
 
+// last pass in workgroup mode: unit ui = (hop group, chunk of LSU outputs); a wave's lanes = (hop within the group, output)
+template <class C>
+__device__ __forceinline__ void mid_last_units(const v2f *img, v2f *out, v2f *sink, int lane, int wave, long long hop0,
+                                               int stride_r, long long limit) {
+    constexpr int r = C::RL, BPL = C::BPL, LSU = C::LSU, HR = 64 / LSU, KC = BPL / LSU;
+    constexpr int NU = (C::NIMG / HR) * KC, UPW = NU / C::NW;
+    const int hs = HR == 1 ? 0 : lane / LSU, kl = lane - hs * LSU;
+    const v2f *base = img + hs * C::IMGS + C::ph(C::pos_of(kl));
+#pragma unroll
+    for (int i = 0; i < UPW; ++i) {
+        const int ui = wave * UPW + i;               // wave-uniform
+        const int hg = ui / KC, c = ui - hg * KC;
+        const int s = hg * HR + hs;                  // image index in the workgroup
+        const long long hop = hop0 + (long long)(s / C::GH) * stride_r + (s % C::GH);
+        v2f *orow = (hop < limit ? out + (size_t)hop * C::M : sink) + kl + LSU * c;
+        const v2f *q = base + hg * HR * C::IMGS + C::ph(C::pos_of(LSU * c));
+        v2f v[r];
+#pragma unroll
+        for (int j = 0; j < r; ++j) v[j] = q[j];
+        bfly(v);
+#pragma unroll
+        for (int k = 0; k < r; ++k) orow[k * BPL] = v[k];
+    }
+}
+
 // the passes of the hop images + their stores.  Wave mode: wave w < NWF owns images [w HPW, (w+1) HPW), no workgroup
 // barrier inside.  Workgroup mode: every thread takes part in every pass (barriers between them), then wave w does the
 // last pass of images [w HPL, (w+1) HPL).  Every wave of the workgroup must call this in workgroup mode.
@@ -396,7 +431,8 @@ __device__ __forceinline__ void mid_transform(v2f *img, const v4f *twp, v2f *out
         }
     } else {
         mid_passes_affine<C, 0, C::TH, C::NIMG, true>(img, twp, lt);
-        mid_last_wave<C>(img + wave * C::HPL * C::IMGS, out, sink, lt & 63, wave * C::HPL, hop_g, stride_r, limit);
+        if constexpr (C::LSU > 0) mid_last_units<C>(img, out, sink, lt & 63, wave, hop_g, stride_r, limit);
+        else mid_last_generic<C, C::NTL, C::NIMG>(img, out, sink, lt, 0, hop_g, stride_r, limit);
     }
 }
 
@@ -627,13 +663,52 @@ int g_diag_stamp_wg = 0;
 
 // ---- host side -------------------------------------------------------------------------------------------------
 
-// (M, R, GH, NWF, WPE, PB, PADN, IMGX, TREG): see MidCfg
+// (M, R, GH, NWF, WPE, PB, PADN, IMGX, TREG, LSP): see MidCfg
 #ifndef WH_MID_320
-#define WH_MID_320 3, 4, 0, 3, 20, 1, 0, 36
+#define WH_MID_320 3, 4, 0, 3, 20, 1, 0, 36, 0
 #endif
 #define WH_MID_X(X, ...) X(__VA_ARGS__)
+// Shapes found by tools/pfb_mid_configs.py (lane utilisation, LDS footprint, simulated bank conflicts):
+//      64: plan [4, 4] waves 4 lanes/hop 4 util 1.00 pass-util 1.00 last-pass lanes/hop 16 LDS 35008 B conflicts rd x1.50 wr x1.00
+//      80: plan [4, 5] waves 4 lanes/hop 5 util 0.94 pass-util 0.94 last-pass lanes/hop 16 LDS 32880 B conflicts rd x2.90 wr x1.00
+//      96: plan [4, 2, 3] waves 4 lanes/hop 6 util 0.94 pass-util 0.94 last-pass lanes/hop 32 LDS 32976 B conflicts rd x1.66 wr x1.31
+//     128: plan [4, 4, 2] waves 4 lanes/hop 8 util 1.00 pass-util 1.00 last-pass lanes/hop 64 LDS 34784 B conflicts rd x1.67 wr x1.67
+//     160: plan [4, 2, 5] waves 4 lanes/hop 10 util 0.94 pass-util 0.94 last-pass lanes/hop 32 LDS 32240 B conflicts rd x1.96 wr x1.50
+//     192: plan [4, 4, 3] waves 4 lanes/hop 12 util 0.94 pass-util 0.94 last-pass lanes/hop 64 LDS 33360 B conflicts rd x2.04 wr x1.31
+//     240: plan [4, 3, 5] waves 4 lanes/hop 10 util 0.94 pass-util 0.62 last-pass lanes/hop 16 LDS 32496 B conflicts rd x1.88 wr x1.58
+//     256: plan [4, 4, 4] waves 4 lanes/hop 16 util 1.00 pass-util 1.00 last-pass lanes/hop 64 LDS 37824 B conflicts rd x2.00 wr x1.33
+//     384: plan [4, 4, 2, 3] waves 8 lanes/hop 24 util 0.94 pass-util 0.94 last-pass lanes/hop 64 LDS 64208 B conflicts rd x1.95 wr x1.47
+//     400: plan [4, 5, 5] waves 5 lanes/hop 20 util 0.94 pass-util 0.75 last-pass lanes/hop 16 LDS 40304 B conflicts rd x1.62 wr x1.35
+//     480: plan [4, 2, 3, 5] waves 4 lanes/hop 20 util 0.94 pass-util 0.62 last-pass lanes/hop 32 LDS 45104 B conflicts rd x1.87 wr x1.64
+//     512: plan [4, 4, 4, 2] waves 4 lanes/hop 32 util 1.00 pass-util 1.00 last-pass lanes/hop 64 LDS 36832 B conflicts rd x2.00 wr x1.50
+//     640: plan [4, 4, 2, 5] waves 8 lanes/hop 40 util 0.94 pass-util 0.94 last-pass lanes/hop 64 LDS 67280 B conflicts rd x1.76 wr x1.33
+//     768: plan [4, 4, 4, 3] waves 12 lanes/hop 64 util 1.00 pass-util 1.00 last-pass lanes/hop 64 LDS 79824 B conflicts rd x2.25 wr x1.50
+//     800: plan [4, 2, 5, 5] waves 10 lanes/hop 40 util 0.94 pass-util 0.75 last-pass lanes/hop 32 LDS 80688 B conflicts rd x1.76 wr x1.66
+//     960: plan [4, 4, 3, 5] waves 4 lanes/hop 40 util 0.94 pass-util 0.62 last-pass lanes/hop 64 LDS 46896 B conflicts rd x1.83 wr x1.69
+//    1280: plan [4, 4, 4, 5] waves 5 lanes/hop 64 util 1.00 pass-util 1.00 last-pass lanes/hop 64 LDS 57520 B conflicts rd x2.25 wr x1.50
+//    2048: plan [4, 4, 4, 4, 2] waves 8 lanes/hop 128 util 1.00 pass-util 1.00 last-pass lanes/hop 64 LDS 77792 B conflicts rd x2.20 wr x1.40
+//    4096: plan [4, 4, 4, 4, 4] waves 16 lanes/hop 512 util 1.00 pass-util 1.00 last-pass lanes/hop 64 LDS 81920 B conflicts rd x3.20 wr x1.60
 #define WH_MID_CONFIGS(X) \
-    WH_MID_X(X, 320, WH_MID_320)
+    WH_MID_X(X, 320, WH_MID_320) \
+    X(64, 16, 4, 0, 3, 16, 1, 0, 36, 0) \
+    X(80, 12, 4, 0, 3, 20, 1, 1, 36, 0) \
+    X(96, 10, 4, 0, 3, 24, 1, 2, 36, 0) \
+    X(128, 8, 4, 0, 3, 32, 1, 2, 36, 0) \
+    X(160, 6, 4, 0, 3, 40, 1, 1, 36, 0) \
+    X(192, 5, 4, 0, 3, 48, 2, 4, 36, 0) \
+    X(240, 4, 4, 0, 3, 60, 1, 3, 36, 10) \
+    X(256, 4, 4, 0, 3, 16, 2, 0, 36, 0) \
+    X(384, 5, 4, 0, 2, 96, 1, 4, 36, 0) \
+    X(400, 3, 4, 0, 2, 100, 1, 0, 36, 20) \
+    X(480, 2, 4, 0, 3, 5, 2, 4, 36, 20) \
+    X(512, 2, 4, 0, 3, 32, 2, 0, 36, 0) \
+    X(640, 3, 4, 0, 2, 40, 2, 3, 36, 0) \
+    X(768, 4, 3, 0, 3, 48, 2, 0, 36, 0) \
+    X(800, 3, 4, 0, 2, 200, 2, 0, 36, 40) \
+    X(960, 1, 4, 0, 3, 5, 2, 4, 36, 40) \
+    X(1280, 1, 5, 0, 2, 80, 2, 0, 36, 0) \
+    X(2048, 1, 4, 0, 2, 32, 2, 0, 36, 0) \
+    X(4096, 1, 2, 0, 2, 1024, 1, 0, 36, 0)
 
 template <class C>
 int mid_launch_t(const PfbMidCall &c, hipStream_t st) {
@@ -700,7 +775,7 @@ namespace wh {
 
 bool pfb_mid_supported(int M, int T) {
     if (T != 9) return false;
-#define X(M_, R_, GH_, NWF_, WPE_, PB_, PADN_, IMGX_, TREG_) if (M == M_) return true;
+#define X(M_, R_, GH_, NWF_, WPE_, PB_, PADN_, IMGX_, TREG_, LSP_) if (M == M_) return true;
     WH_MID_CONFIGS(X)
 #undef X
     return false;
@@ -708,8 +783,8 @@ bool pfb_mid_supported(int M, int T) {
 
 int pfb_mid_launch(int M, int T, const PfbMidCall &c, hipStream_t st) {
     if (T == 9) {
-#define X(M_, R_, GH_, NWF_, WPE_, PB_, PADN_, IMGX_, TREG_) \
-    if (M == M_) return mid_launch_t<MidCfg<M_, 9, R_, GH_, NWF_, WPE_, PB_, PADN_, IMGX_, TREG_>>(c, st);
+#define X(M_, R_, GH_, NWF_, WPE_, PB_, PADN_, IMGX_, TREG_, LSP_) \
+    if (M == M_) return mid_launch_t<MidCfg<M_, 9, R_, GH_, NWF_, WPE_, PB_, PADN_, IMGX_, TREG_, LSP_>>(c, st);
         WH_MID_CONFIGS(X)
 #undef X
     }
