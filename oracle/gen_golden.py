@@ -574,6 +574,53 @@ def gen_nid():
     save("nid", **out)
 
 
+def gen_chain4():
+    """Config 4, chained: IQ -> C4FMDemodulator.demodulate (dsp/p25/c4fm.py:2528) -> P25P1MessageFramer.process_batch
+    (decoders/p25_framer.py:471-617), fed in 100 ms calls as cli.py:700-716 / decoders/p25.py:1961 do: every BCH
+    attempt and every NID event of the reference on a carrier that transmits frame heads."""
+    from wavecapsdr.decoders import p25_framer as rfr
+
+    fs, call = 48000, 4800
+    out = {}
+    for ci, (seed, snr, foff) in enumerate(((1500, 20.0, 150.0), (1520, 12.0, -310.0))):
+        iq, tx = S.p25_head_stream_iq(fs, seed, 3, snr, foff)
+        dem = rc4.C4FMDemodulator(sample_rate=fs)
+        fr = rfr.P25P1MessageFramer()
+        fr.start()
+        log = []
+        real = rfr.bch_decode
+
+        def spy(cw, tn=None):
+            r = real(cw, tn)
+            log.append((fr._debug_symbol_count - 1, int(r[0]), int(r[1]), int(tn or 0)))
+            return r
+
+        rfr.bch_decode = spy
+        counts, dibs, softs = [], [], []
+        try:
+            for s0 in range(0, len(iq), call):
+                d, sf = dem.demodulate(iq[s0:s0 + call])
+                counts.append(len(d)); dibs.append(np.asarray(d, dtype=np.uint8)); softs.append(np.asarray(sf, dtype=np.float32))
+                if len(d):
+                    try:
+                        fr.process_batch(np.asarray(sf, dtype=np.float32), np.asarray(d, dtype=np.uint8))
+                    except Exception:      # message assembly downstream of the NID is not part of this row
+                        pass
+        finally:
+            rfr.bch_decode = real
+        ev = np.array([(i, (d >> 4) & 0xFFF, d & 0xF, e) for i, d, e, _ in log if e >= 0], dtype=np.int64).reshape(-1, 4)
+        out[f"c{ci}_args"] = np.array([fs, call, seed, int(snr * 10), int(foff * 10), 3], dtype=np.int64)
+        out[f"c{ci}_sha"] = np.array(S.sha256(iq))
+        out[f"c{ci}_counts"] = np.array(counts, dtype=np.int32)
+        out[f"c{ci}_dibits"] = np.concatenate(dibs)
+        out[f"c{ci}_soft"] = np.concatenate(softs)
+        out[f"c{ci}_attempts"] = np.array(log, dtype=np.int64).reshape(-1, 4)
+        out[f"c{ci}_events"] = ev
+        print(f"chain4 case {ci}: {len(iq)} samples, {sum(counts)} dibits, {len(log)} BCH attempts, {len(ev)} NID events")
+    out["n_cases"] = np.array(2)
+    save("chain4", **out)
+
+
 def gen_blanker():
     """A14: noise_blanker (dsp/filters.py:267-343) on float32 audio with impulses; even and odd lengths."""
     from wavecapsdr.dsp.filters import noise_blanker
@@ -724,7 +771,7 @@ def gen_lsm():
     save("lsm", **out)
 
 
-ALL = dict(blanker=gen_blanker, nid=gen_nid, classifier=gen_classifier, recorder=gen_recorder, nr=gen_nr, sam=gen_sam, rawdig=gen_rawdig, lsm=gen_lsm, framer=gen_framer, cqpsk=gen_cqpsk, trunk=gen_trunk, a1=gen_a1, a2=gen_a2, a3=gen_a3, a6=gen_a6, chain=gen_chain, a7=gen_a7, a8=gen_a8, c4fm=gen_c4fm)
+ALL = dict(chain4=gen_chain4, blanker=gen_blanker, nid=gen_nid, classifier=gen_classifier, recorder=gen_recorder, nr=gen_nr, sam=gen_sam, rawdig=gen_rawdig, lsm=gen_lsm, framer=gen_framer, cqpsk=gen_cqpsk, trunk=gen_trunk, a1=gen_a1, a2=gen_a2, a3=gen_a3, a6=gen_a6, chain=gen_chain, a7=gen_a7, a8=gen_a8, c4fm=gen_c4fm)
 
 if __name__ == "__main__":
     import logging

@@ -134,15 +134,22 @@ def c4fm_iq(
     frame_len: int = 360,
     amp: float = 0.5,
     silence: tuple[int, int] | None = None,
+    dibits: np.ndarray | None = None,
 ) -> tuple[np.ndarray, np.ndarray]:
     """RRC-shaped C4FM at complex baseband (deviation: symbol 3 -> 1800 Hz).
 
     Returns (iq complex64[n], transmitted dibits).  ``silence=(a, b)`` replaces
-    samples a..b by noise only (exercises fine-sync loss).
+    samples a..b by noise only (exercises fine-sync loss).  ``dibits`` replaces the
+    repeating TSDU-like frames by an explicit dibit sequence (padded with random dibits).
     """
     sps = fs / symbol_rate
     n_sym = int(np.ceil(n / sps)) + 24
-    dib = c4fm_frames_dibits(n_sym, seed, frame_len)
+    if dibits is None:
+        dib = c4fm_frames_dibits(n_sym, seed, frame_len)
+    else:
+        dib = np.random.default_rng(seed + 31).integers(0, 4, size=n_sym, dtype=np.uint8)
+        k = min(n_sym, len(dibits))
+        dib[:k] = np.asarray(dibits, dtype=np.uint8)[:k]
     sym = _DIBIT_TO_SYMBOL[dib]
     # frequency waveform f(t) = 600 Hz * sum_k a_k p(t/T - k), RRC pulse alpha 0.2, +-8 symbols
     tn = np.arange(n, dtype=np.float64) / sps
@@ -164,6 +171,20 @@ def c4fm_iq(
         a, b = silence
         iq[a:b] = 0.0
     return (iq + noise).astype(np.complex64), dib
+
+
+def p25_head_stream_iq(fs: int = 48000, seed: int = 1500, reps: int = 3, snr_db: float = 20.0,
+                       freq_offset_hz: float = 150.0):
+    """IQ of a C4FM carrier whose dibits are `reps` different frame-head streams (nid_stream: sync + BCH-coded NID with
+    the status dibit, clean / corrupted / restarted heads) behind a 200-dibit preamble of TSDU-like frames for the
+    demodulator to lock on -- the input of the chained check IQ -> C4FM demodulator -> soft sync -> NID / BCH."""
+    parts = [c4fm_frames_dibits(200, seed)]
+    for r in range(reps):
+        parts.append(nid_stream(seed + 10 * r)[0])
+    dib = np.concatenate(parts)
+    n = int(np.ceil((len(dib) + 8) * fs / 4800.0))
+    iq, tx = c4fm_iq(n, fs, seed, snr_db=snr_db, freq_offset_hz=freq_offset_hz, dibits=dib)
+    return iq, tx
 
 
 # --------------------------------------------------------------------------

@@ -59,3 +59,22 @@ def test_c4fm_oracle_reset_and_empty(golden):
     assert np.array_equal(a1, a2) and np.array_equal(s1, s2)
     e = d.demodulate(np.empty(0, np.complex64))
     assert e[0].size == 0 and e[1].size == 0
+
+
+@pytest.mark.parametrize("atan_mode", [0, 1])
+def test_c4fm_oracle_matches_reference_on_the_frame_head_carrier(golden, atan_mode):
+    """The config-4 chain golden (IQ of a carrier transmitting frame heads -> reference demodulator -> reference framer):
+    the C oracle reproduces the reference demodulator's dibits and soft symbols on both cases, 100 ms calls."""
+    g = golden("chain4")
+    for ci in range(int(g["n_cases"])):
+        fs, call, seed, snr10, foff10, reps = (int(v) for v in g[f"c{ci}_args"])
+        iq, _ = S.p25_head_stream_iq(fs, seed, reps, snr10 / 10.0, foff10 / 10.0)
+        assert S.sha256(iq) == str(g[f"c{ci}_sha"])
+        d = C4FMDemodulatorRef(sample_rate=fs, atan_mode=atan_mode)
+        dib, soft, counts = [], [], []
+        for s in range(0, len(iq), call):
+            a, b = d.demodulate(iq[s:s + call])
+            dib.append(a); soft.append(b); counts.append(len(a))
+        assert np.array_equal(np.array(counts, dtype=np.int32), g[f"c{ci}_counts"]), ci
+        assert np.array_equal(np.concatenate(dib), g[f"c{ci}_dibits"]), ci
+        assert peak_rel_err(np.concatenate(soft), g[f"c{ci}_soft"]) <= 1e-5, ci

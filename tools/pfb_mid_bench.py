@@ -22,18 +22,21 @@ def timeit(ch, x, out, reps=10):
 
 for M in MS:
     fs, bw = M * 25_000, 25_000
-    sh = wavehip.PolyphaseChannelizer(fs, bw)
+    sh = wavehip.PolyphaseChannelizer(fs, bw).tune(path='shaped')
     assert sh.channel_count == M
     g = torch.Generator(device="cuda").manual_seed(M)
-    for logn in (24, 26):
+    for logn in ((24, 26, 28) if M == 1024 else (24, 26)):
         n = 1 << logn
         x = torch.view_as_complex(torch.randn(n, 2, device="cuda", generator=g).mul_(0.5))
         out = torch.empty((sh.hops(n), M), dtype=torch.complex64, device="cuda")
         t = timeit(sh, x, out)
         line = f"M={M:5d} n=2^{logn}: shaped {t*1e6:8.1f} us = {n*24/t/1e12:5.2f} TB/s"
         try:
-            old = wavehip.PolyphaseChannelizer(fs, bw).tune(path="run")
-            name = "run kernel"
+            if M == 1024:
+                old, name = wavehip.PolyphaseChannelizer(fs, bw), "pfb1024 kernel"
+            else:
+                old = wavehip.PolyphaseChannelizer(fs, bw).tune(path="run")
+                name = "run kernel"
         except RuntimeError:
             old = wavehip.PolyphaseChannelizer(fs, bw).tune(path="per_hop")
             name = "per-hop kernel"

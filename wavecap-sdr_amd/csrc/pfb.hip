@@ -990,7 +990,7 @@ static int pfb_run_fmt(wh_pfb *p, const void *d_iq, int fmt, size_t n, float *d_
     if (H == 0) return WH_OK;
     if (!d_iq || !d_out) return set_err(WH_E_ARG, "wh_pfb_run: null buffer");
     int rc;
-    const bool fast = (p->M == FM && p->T == FT) && p->path != 1;
+    const bool fast = (p->M == FM && p->T == FT) && p->path != 1 && !(p->path == 3 && p->mid_ok);
     if (!fast && p->mid_ok && (p->path == 0 || p->path == 3)) {
         // one launch: head hops, runs and the history update (pfb_mid.hip)
         PfbMidCall c;

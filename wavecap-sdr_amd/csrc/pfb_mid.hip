@@ -690,6 +690,7 @@ int g_diag_stamp_wg = 0;
 //    4096: plan [4, 4, 4, 4, 4] waves 16 lanes/hop 512 util 1.00 pass-util 1.00 last-pass lanes/hop 64 LDS 81920 B conflicts rd x3.20 wr x1.60
 #define WH_MID_CONFIGS(X) \
     WH_MID_X(X, 320, WH_MID_320) \
+    X(1024, 1, 4, 0, 3, 16, 2, 0, 36, 0) \
     X(64, 16, 4, 0, 3, 16, 1, 0, 36, 0) \
     X(80, 12, 4, 0, 3, 20, 1, 1, 36, 0) \
     X(96, 10, 4, 0, 3, 24, 1, 2, 36, 0) \
