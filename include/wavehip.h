@@ -137,6 +137,12 @@ typedef struct wh_chanbank_cfg {
 int wh_chanbank_create(wh_chanbank **out, const wh_chanbank_cfg *cfg);
 int wh_chanbank_run(wh_chanbank *b, const void *d_in, size_t n_chunks, float *d_audio, float *d_metrics,
                     void *stream);
+/* same, and the audio additionally leaves in its wire format (N4, capture.py:119-144), written by the finalize kernel:
+ * wire_format 1: d_wire int16 [n_chunks][K][n_out] by the pack_pcm16 rule (clip to [-1, 1], x 32767, truncate);
+ * wire_format 2: d_wire float32 clipped to [-1, 1] (pack_f32); 0: none (d_wire ignored).  Squelched rows are zeros in
+ * both buffers.  Only d_wire (and the 16-byte metrics rows) need to cross PCIe. */
+int wh_chanbank_run_wire(wh_chanbank *b, const void *d_in, size_t n_chunks, float *d_audio, float *d_metrics,
+                         int wire_format, void *d_wire, void *stream);
 size_t wh_chanbank_workspace_bytes(const wh_chanbank *b, size_t n_chunks);
 void wh_chanbank_destroy(wh_chanbank *b);
 

@@ -1,0 +1,163 @@
+"""The batched seam (wavehip.process_channels_parallel, drop-in for Capture._process_channels_parallel,
+capture.py:2489-2597) with stand-ins for Capture / Channel that carry exactly the attributes the seam touches.  The first
+test re-expresses the reference's own seam test (backend/tests/unit/test_capture_dsp_timeout.py:10-29: a slow operator
+and a 10 ms timeout must give (channel, None) quickly); oracle/check_boundary.py runs the same scenario against the
+real reference Capture in the build container."""
+
+import threading
+import time
+from concurrent.futures import ThreadPoolExecutor
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+
+class FakeChannel:
+    def __init__(self, cid, mode="wbfm", state="running"):
+        self.cfg = SimpleNamespace(id=cid, capture_id="c1", mode=mode, offset_hz=0.0)
+        self.state = state
+        self.rssi_db = None
+        self.signal_power_db = None
+        self.audio_seen = []
+
+    def _update_audio_metrics(self, audio):
+        self.audio_seen.append(audio)
+
+
+class FakeCapture:
+    def __init__(self, channels):
+        self.cfg = SimpleNamespace(id="c1", sample_rate=1_000_000)
+        self._channels = {c.cfg.id: c for c in channels}
+        self._dsp_inflight_lock = threading.Lock()
+        self._dsp_inflight = 0
+        self._dsp_drop_last_log = 0.0
+        self.stateful_calls = []
+
+    def _apply_stateful_processing(self, ch, audio, samples):
+        self.stateful_calls.append(ch.cfg.id)
+        if ch.cfg.id == "boom":
+            raise RuntimeError("decoder failed")
+        return audio
+
+
+@pytest.fixture()
+def seam():
+    import wavehip.capture_seam as s
+    return s
+
+
+def test_process_channels_parallel_timeout(seam, monkeypatch):
+    channel = FakeChannel("ch1")
+    capture = FakeCapture([channel])
+
+    def slow_dsp(_capture, _samples, _cfgs):
+        time.sleep(0.1)
+        return [(None, {})]
+
+    monkeypatch.setattr(seam, "dispatch_chunk", slow_dsp)
+    samples = np.zeros(1000, dtype=np.complex64)
+    with ThreadPoolExecutor(max_workers=1) as executor:
+        start = time.perf_counter()
+        results = seam.process_channels_parallel(capture, samples, executor, timeout=0.01)
+        elapsed = time.perf_counter() - start
+    assert len(results) == 1
+    result_channel, result_audio = results[0]
+    assert result_channel is channel
+    assert result_audio is None
+    assert elapsed < 0.2
+    assert capture._dsp_inflight == 0      # released when the late job ended
+
+
+def test_results_order_metrics_stateful_tail_and_errors(seam, monkeypatch):
+    chans = [FakeChannel("a"), FakeChannel("stopped", state="stopped"), FakeChannel("boom"), FakeChannel("b")]
+    capture = FakeCapture(chans)
+    audio_a, audio_b = np.ones(8, np.float32), np.full(8, 2.0, np.float32)
+
+    def dsp(_capture, _samples, cfgs):
+        assert [c.id for c in cfgs] == ["a", "boom", "b"]          # running channels only, capture order
+        return [(audio_a, {"rssi_db": -30.0, "signal_power_db": -12.0}), (np.zeros(8, np.float32), {"rssi_db": -50.0}),
+                (audio_b, {"rssi_db": -40.0})]
+
+    monkeypatch.setattr(seam, "dispatch_chunk", dsp)
+    with ThreadPoolExecutor(max_workers=3) as ex:
+        res = seam.process_channels_parallel(capture, np.zeros(100, np.complex64), ex, timeout=1.0)
+    assert [(c.cfg.id, a is not None) for c, a in res] == [("a", True), ("boom", False), ("b", True)]
+    assert res[0][1] is audio_a and res[2][1] is audio_b
+    assert chans[0].rssi_db == -30.0 and chans[0].signal_power_db == -12.0 and chans[3].rssi_db == -40.0
+    assert chans[3].signal_power_db is None
+    assert capture.stateful_calls == ["a", "boom", "b"] and len(chans[0].audio_seen) == 1 and not chans[2].audio_seen
+
+
+def test_backlog_skips_the_cycle_and_operator_exception_drops_audio(seam, monkeypatch):
+    capture = FakeCapture([FakeChannel("a")])
+    capture._dsp_inflight = 8                         # max(4, 2 x 3 workers) = 6 already in flight
+    with ThreadPoolExecutor(max_workers=3) as ex:
+        assert seam.process_channels_parallel(capture, np.zeros(10, np.complex64), ex) == []
+    capture._dsp_inflight = 0
+
+    def broken(_c, _s, _cfgs):
+        raise RuntimeError("launch failed")
+
+    monkeypatch.setattr(seam, "dispatch_chunk", broken)
+    with ThreadPoolExecutor(max_workers=3) as ex:
+        res = seam.process_channels_parallel(capture, np.zeros(10, np.complex64), ex)
+    assert len(res) == 1 and res[0][1] is None and capture._dsp_inflight == 0
+    assert seam.process_channels_parallel(FakeCapture([]), np.zeros(10, np.complex64), None) == []
+
+
+@pytest.mark.gpu
+def test_seam_runs_the_batched_dispatcher_on_the_device():
+    """Through the real dispatcher: three NBFM channels + one digital-voice channel of one capture, one upload; audio equal
+    to the single-channel operator's, metrics on the channel objects."""
+    import signals as S
+    import wavehip
+
+    fs, n = 2_400_000, 120_000
+    offs = S.nbfm_bank_offsets(4)
+    iq = S.nbfm_bank_c64(n, fs, seed=21, n_ch=4)
+    chans = []
+    for k in range(3):
+        c = FakeChannel(f"n{k}")
+        c.cfg = wavehip.ChannelConfig(id=f"n{k}", mode="nbfm", offset_hz=offs[k], enable_deemphasis=False)
+        chans.append(c)
+    d = FakeChannel("p25")
+    d.cfg = wavehip.ChannelConfig(id="p25", mode="p25", offset_hz=offs[3])
+    chans.append(d)
+    capture = FakeCapture(chans)
+    capture.cfg.sample_rate = fs
+    with ThreadPoolExecutor(max_workers=3) as ex:
+        res = wavehip.process_channels_parallel(capture, iq, ex, timeout=30.0)
+    assert [c.cfg.id for c, _ in res] == ["n0", "n1", "n2", "p25"]
+    for k in range(3):
+        a_ref, m_ref = wavehip.process_channel_dsp_stateless(iq, fs, chans[k].cfg)
+        assert np.array_equal(res[k][1], a_ref) and chans[k].rssi_db == m_ref["rssi_db"]
+    assert res[3][1] is None and chans[3].rssi_db is not None
+
+
+@pytest.mark.gpu
+def test_wire_formats_written_by_the_finalize_kernel():
+    """ChannelBank(..., wire="pcm16" | "f32"): the int16 / clipped-float32 buffers the finalize kernel writes are
+    byte-identical to pack_pcm16 / pack_f32 (capture.py:119-144 rules, pinned by the A1 / N4 goldens) of the float32
+    audio of the same call -- squelched rows and a 200-chunk batch included."""
+    import torch
+    import signals as S
+    import wavehip
+
+    fs, n, K = 2_400_000, 120_000, 4
+    offs = S.nbfm_bank_offsets(K)
+    i16 = S.pack_iq16_np(S.nbfm_bank_c64(n, fs, seed=22, n_ch=K))
+    cfgs = [wavehip.ChannelConfig(mode="nbfm", offset_hz=o, enable_deemphasis=False,
+                                  squelch_db=(0.0 if k == 2 else None)) for k, o in enumerate(offs)]
+    bank = wavehip.ChannelBank(fs, n, cfgs, input_format="int16", apply_squelch=True)
+    d = torch.from_numpy(np.tile(i16, 3)).cuda()
+    for wire, pack in (("pcm16", wavehip.pack_pcm16), ("f32", wavehip.pack_f32)):
+        audio, met, w = bank.process_device(d, 3, wire=wire)
+        a = audio.cpu().numpy()
+        assert not a[:, 2].any() and a[:, 0].any()                      # channel 2 squelched (rssi < 0 dB), others not
+        assert w.cpu().numpy().tobytes() == pack(a.reshape(-1))
+        assert torch.equal(audio, bank.process_device(d, 3)[0])          # the float32 audio is unchanged by the wire pass
+    res = bank.process_wire(i16, "pcm16")
+    ref = bank.process(i16)
+    for (wb, m), (a, m2) in zip(res, ref):
+        assert wb == wavehip.pack_pcm16(a) and m == m2

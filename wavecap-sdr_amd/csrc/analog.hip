@@ -903,11 +903,23 @@ __global__ __launch_bounds__(64) void chan_rows_scan_kernel(float *rows, double 
 
 // finalize.  post 0 (FM): scale by 0.18/rms (dsp/fm.py:42-62) + soft clip x0.95 (fm.py:26-39);
 // post 1 (AM/SSB with AGC): audio as is;  post 2 (AM/SSB without AGC): agc.soft_clip (agc.py:58-70)
+// wire != 0: the audio additionally leaves in its wire format (N4): 1 = int16 PCM by the pack_pcm16 rule (capture.py:119-131:
+// clip to [-1, 1], x 32767, truncate), 2 = float32 clipped to [-1, 1] (pack_f32, capture.py:134-144), written to wire_out
+// [rows][n_out] -- what the caller sends on needs no second pass and only that buffer has to cross PCIe.
 __global__ __launch_bounds__(256) void fmbank_finalize_kernel(float *audio, const double *acc, float *metrics,
                                                               int N, int n_fm, int n_out, int post,
-                                                              const float *squelch_db, int K) {
+                                                              const float *squelch_db, int K, int wire, void *wire_out) {
     const size_t row = blockIdx.x;
     float *au = audio + row * n_out;
+    // squelch (capture.py:2918-2921): rssi below the channel's threshold -> zeros (metrics keep the unsquelched power)
+    bool squelched = false;
+    if (squelch_db) {
+        const float sq = squelch_db[row % K];
+        const float rssi = (float)(10.0 * log10(acc[row * 2] / (double)N + 1e-10));
+        squelched = sq == sq && rssi < sq;   // NaN = no squelch configured
+    }
+    short *w16 = wire == 1 ? reinterpret_cast<short *>(wire_out) + row * n_out : nullptr;
+    float *w32 = wire == 2 ? reinterpret_cast<float *>(wire_out) + row * n_out : nullptr;
     const double *ac = acc + row * 2;
     float s = 1.0f;
     if (post == 0) {
@@ -922,10 +934,13 @@ __global__ __launch_bounds__(256) void fmbank_finalize_kernel(float *audio, cons
         float v = au[i];
         if (post == 0) v = tanhf((v * s) * 1.5f) * NORM * 0.95f;
         else if (post == 2) v = tanhf(v * 1.5f) * NORM;
-        au[i] = v;
         p += v * v;
         mx = fmaxf(mx, fabsf(v));
         if (!(fabsf(v) <= 3.0e38f)) bad = 1;
+        if (squelched) v = 0.0f;
+        au[i] = v;
+        if (w16) w16[i] = pack1(v);
+        if (w32) w32[i] = v != v ? v : fminf(fmaxf(v, -1.0f), 1.0f);   // np.clip keeps NaN
     }
     __shared__ float rp[4], rm[4];
     __shared__ int rb[4];
@@ -949,15 +964,6 @@ __global__ __launch_bounds__(256) void fmbank_finalize_kernel(float *audio, cons
         m[1] = (float)(10.0 * log10((double)(p / (float)n_out) + 1e-10));
         m[2] = mx;
         m[3] = bad ? 0.f : 1.f;
-    }
-    // squelch (capture.py:2918-2921): rssi below the channel's threshold -> zeros (metrics keep the unsquelched power)
-    if (squelch_db) {
-        const float sq = squelch_db[row % K];
-        const float rssi = (float)(10.0 * log10(ac[0] / (double)N + 1e-10));
-        if (sq == sq && rssi < sq) {   // NaN = no squelch configured
-            __syncthreads();
-            for (int i = threadIdx.x; i < n_out; i += 256) au[i] = 0.0f;
-        }
     }
 }
 
@@ -1423,9 +1429,16 @@ extern "C" size_t wh_chanbank_workspace_bytes(const wh_chanbank *b, size_t n_chu
 
 extern "C" int wh_chanbank_run(wh_chanbank *b, const void *d_in, size_t n_chunks, float *d_audio, float *d_metrics,
                                void *stream) {
+    return wh_chanbank_run_wire(b, d_in, n_chunks, d_audio, d_metrics, 0, nullptr, stream);
+}
+
+extern "C" int wh_chanbank_run_wire(wh_chanbank *b, const void *d_in, size_t n_chunks, float *d_audio, float *d_metrics,
+                                    int wire_format, void *d_wire, void *stream) {
     if (!b) return set_err(WH_E_ARG, "wh_chanbank_run: null handle");
     if (n_chunks == 0) return WH_OK;
     if (!d_in || !d_audio || !d_metrics) return set_err(WH_E_ARG, "wh_chanbank_run: null buffer");
+    if (wire_format < 0 || wire_format > 2 || (wire_format != 0 && !d_wire))
+        return set_err(WH_E_ARG, "wh_chanbank_run_wire: wire_format 0 (none) / 1 (int16 PCM) / 2 (clipped float32) with a buffer");
     if (n_chunks > 65535) return set_err(WH_E_ARG, "wh_chanbank_run: n_chunks > 65535 per call");
     hipStream_t st = as_stream(stream);
     const wh_chanbank_cfg &c = b->cfg;
@@ -1572,7 +1585,8 @@ extern "C" int wh_chanbank_run(wh_chanbank *b, const void *d_in, size_t n_chunks
         }
     }
     hipLaunchKernelGGL(fmbank_finalize_kernel, dim3((unsigned)rows), dim3(256), 0, st, d_audio, b->d_acc, d_metrics,
-                       c.chunk_len, b->nr ? b->nr_len : c.chunk_len, c.n_out, b->post, b->d_squelch, c.n_channels);
+                       c.chunk_len, b->nr ? b->nr_len : c.chunk_len, c.n_out, b->post, b->d_squelch, c.n_channels, wire_format,
+                       d_wire);
     WH_LAUNCH_CHECK();
     return WH_OK;
 }

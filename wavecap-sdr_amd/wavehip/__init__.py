@@ -17,6 +17,7 @@ from .channelizer import PolyphaseChannelizer, ChannelCalculator  # noqa: F401
 from .fft_backend import HipFFTBackend, FFTResult, FFTBackend, is_available, register_with  # noqa: F401
 from .channel_ops import (ChannelBank, ChannelConfig, ChannelDispatcher, process_channel_dsp_stateless,  # noqa: F401
                           update_signal_metrics, noise_blanker)
+from .capture_seam import process_channels_parallel  # noqa: F401
 from .wire import pack_iq16, unpack_iq16, pack_pcm16, pack_f32  # noqa: F401
 from .framer import P25P1SoftSyncDetector, SoftSyncBank, P25NIDFrontEnd, NACTracker  # noqa: F401
 from .fec import BCHDecoder, bch_decode  # noqa: F401
@@ -29,6 +30,6 @@ from .trunking import (TrunkingDDC, TrunkingDDCBank, ScannerMeasure, decimation_
 
 __all__ = [
     "PolyphaseChannelizer", "ChannelCalculator", "HipFFTBackend", "FFTResult", "FFTBackend", "is_available",
-    "register_with", "ChannelBank", "ChannelConfig", "ChannelDispatcher", "noise_blanker", "process_channel_dsp_stateless", "update_signal_metrics", "pack_iq16", "unpack_iq16",
+    "register_with", "process_channels_parallel", "ChannelBank", "ChannelConfig", "ChannelDispatcher", "noise_blanker", "process_channel_dsp_stateless", "update_signal_metrics", "pack_iq16", "unpack_iq16",
     "pack_pcm16", "pack_f32", "P25P1SoftSyncDetector", "SoftSyncBank", "P25NIDFrontEnd", "NACTracker", "BCHDecoder", "bch_decode", "C4FMBank", "C4FMDemodulator", "c4fm_demod_simple", "CQPSKBank", "CQPSKDemodulator", "GardnerBank", "GardnerTED", "LSMBank", "LSMDemodulator", "ChannelClassifier", "ClassifiedChannel", "TrunkingDDC", "TrunkingDDCBank", "ScannerMeasure", "decimation_plan", "recorder_decimation_plan",
 ]

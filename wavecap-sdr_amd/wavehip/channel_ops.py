@@ -41,14 +41,19 @@ NR_FFT_SIZE = 1024   # dsp/filters.py:350
 
 @dataclass
 class ChannelConfig:
-    """Mirror of the DSP fields of capture.py:442-501 (same names and defaults; the reference's
-    own ChannelConfig instances are accepted as-is, this class exists for standalone use)."""
+    """Mirror of capture.py:440-501 (same field names and defaults -- the build-container boundary check compares them with the
+    reference's dataclass; the reference's own ChannelConfig instances are accepted as-is, this class exists for
+    standalone use, so `id` / `capture_id` have defaults here).  Like the reference's dispatcher (capture.py:340-414)
+    the operator does not forward agc_attack_ms / agc_release_ms / enable_noise_blanker; name, RDS and POCSAG fields
+    belong to the lifecycle around the operator."""
 
     id: str = "ch"
     capture_id: str = "cap"
     mode: str = "nbfm"
     offset_hz: float = 0.0
     audio_rate: int = 48_000
+    name: str | None = None
+    auto_name: str | None = None
     enable_deemphasis: bool = True
     deemphasis_tau_us: float = 75.0
     enable_mpx_filter: bool = True
@@ -68,12 +73,19 @@ class ChannelConfig:
     ssb_bfo_offset_hz: float = 1500.0
     enable_agc: bool = False
     agc_target_db: float = -20.0
+    agc_attack_ms: float = 5.0
+    agc_release_ms: float = 50.0
+    enable_noise_blanker: bool = False
+    noise_blanker_threshold_db: float = 10.0
     notch_frequencies: list = field(default_factory=list)
     enable_noise_reduction: bool = False
     noise_reduction_db: float = 12.0
     squelch_db: float | None = None
     sam_sideband: str = "dsb"
     sam_pll_bandwidth_hz: float = 50.0
+    enable_rds: bool = True
+    enable_pocsag: bool = False
+    pocsag_baud: int = 1200
 
 
 def resample_design(in_rate: int, out_rate: int):
@@ -347,9 +359,14 @@ class ChannelBank:
             destroy(h)
             self._h = None
 
-    def process_device(self, d_in, n_chunks: int, audio=None, metrics=None):
+    WIRE = {None: 0, "pcm16": 1, "f32": 2}
+
+    def process_device(self, d_in, n_chunks: int, audio=None, metrics=None, wire: str | None = None, wire_out=None):
         """d_in: GPU tensor holding n_chunks*chunk_len samples (complex64, or int16 pairs).
-        Returns (audio f32 [n_chunks, K, n_out], metrics f32 [n_chunks, K, 4]) on the GPU."""
+        Returns (audio f32 [n_chunks, K, n_out], metrics f32 [n_chunks, K, 4]) on the GPU; with wire="pcm16" / "f32"
+        a third tensor [n_chunks, K, n_out] holds the audio in its wire format (int16 by the pack_pcm16 rule / float32
+        clipped to [-1, 1], capture.py:119-144), written by the finalize kernel itself -- the only buffer that has
+        to cross PCIe."""
         torch = self._torch
         assert d_in.is_cuda and d_in.is_contiguous()
         if self.input_format == 0:
@@ -360,9 +377,41 @@ class ChannelBank:
             audio = torch.empty((n_chunks, self.K, self.n_out), dtype=torch.float32, device=d_in.device)
         if metrics is None:
             metrics = torch.empty((n_chunks, self.K, 4), dtype=torch.float32, device=d_in.device)
-        _lib.check(_lib.lib.wh_chanbank_run(self._h, d_in.data_ptr(), n_chunks, audio.data_ptr(), metrics.data_ptr(),
-                                            _lib.stream_ptr(torch)), "wh_chanbank_run")
-        return audio, metrics
+        if wire is None:
+            _lib.check(_lib.lib.wh_chanbank_run(self._h, d_in.data_ptr(), n_chunks, audio.data_ptr(), metrics.data_ptr(),
+                                                _lib.stream_ptr(torch)), "wh_chanbank_run")
+            return audio, metrics
+        fmt = self.WIRE[wire]
+        if wire_out is None:
+            wire_out = torch.empty((n_chunks, self.K, self.n_out), dtype=torch.int16 if fmt == 1 else torch.float32,
+                                   device=d_in.device)
+        _lib.check(_lib.lib.wh_chanbank_run_wire(self._h, d_in.data_ptr(), n_chunks, audio.data_ptr(), metrics.data_ptr(),
+                                                 fmt, wire_out.data_ptr(), _lib.stream_ptr(torch)), "wh_chanbank_run_wire")
+        return audio, metrics, wire_out
+
+    def process_wire(self, samples, wire: str = "pcm16") -> list[tuple[bytes | None, dict[str, Any]]]:
+        """One chunk (host array) -> [(wire bytes | None, metrics)] per channel: what capture.py:884-948 hands to its
+        audio sinks (pack_pcm16 / pack_f32 of the operator's audio), with only the wire buffer and the metrics
+        downloaded.  Same validation conventions as process()."""
+        torch = self._torch
+        x = np.ascontiguousarray(samples, dtype=np.complex64 if self.input_format == 0 else np.int16)
+        n = x.shape[0] // (1 if self.input_format == 0 else 2)
+        if n != self.chunk_len:
+            raise ValueError(f"ChannelBank.process_wire: expected {self.chunk_len} samples, got {n}")
+        if self.input_format == 0 and not np.isfinite(x.view(np.float32)).all():  # capture.py:323-325
+            logger.warning("ChannelBank: non-finite IQ samples, dropping DSP chunk")
+            return [(None, {}) for _ in range(self.K)]
+        _, met_dev, w_dev = self.process_device(torch.from_numpy(x).cuda(), 1, wire=wire)
+        met, w = met_dev[0].cpu().numpy(), w_dev[0].cpu().numpy()
+        out = []
+        for k in range(self.K):
+            m: dict[str, Any] = {"rssi_db": float(met[k, 0])}
+            if met[k, 3] < 0.5 or met[k, 2] > AUDIO_MAX_ABS:  # validation.py:41-52
+                out.append((None, m))
+                continue
+            m["signal_power_db"] = float(met[k, 1])
+            out.append((w[k].tobytes(), m))
+        return out
 
     def process(self, samples) -> list[tuple[np.ndarray | None, dict[str, Any]]]:
         """One chunk (host array) -> [(audio | None, metrics)] per channel, reference conventions."""
