@@ -188,6 +188,15 @@ def test_n1_signal_metrics(wh, golden, O):
     for got, off in zip(r2, (0.0, offs[3])):
         rssi, snr = O.update_signal_metrics(z, fs, off)
         assert abs(got["rssi_db"] - rssi) <= 2e-4 and abs(got["snr_db"] - snr) <= 2e-4
+    # one ranking of |iq| for all channels (no mix: |freq_shift(iq)| = |iq| up to float32 rounding) against the
+    # reference goldens of three channels, and through the dispatcher (one upload, snr_db on every channel)
+    sh = wh.update_signal_metrics(iq, fs, offs, shared_magnitudes=True)
+    for row, k in zip(g["sigmet"], (0, 13, 31)):
+        assert abs(sh[k]["rssi_db"] - row[0]) <= 2e-4 and abs(sh[k]["snr_db"] - row[1]) <= 2e-4
+    cfgs = [wh.ChannelConfig(mode="nbfm", offset_hz=offs[k], enable_deemphasis=False) for k in (0, 13, 31)]
+    out = wh.ChannelDispatcher(fs).process(iq, cfgs, snr=True)
+    for (audio, m), row in zip(out, g["sigmet"]):
+        assert audio is not None and abs(m["rssi_db"] - row[0]) <= 2e-4 and abs(m["snr_db"] - row[1]) <= 2e-4
 
 
 def test_chain_wbfm(wh, golden):

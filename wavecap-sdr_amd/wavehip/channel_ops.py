@@ -443,11 +443,20 @@ class ChannelBank:
         return out
 
 
-def update_signal_metrics(samples, sample_rate: int, offsets_hz, input_format: str = "cf32") -> list[dict[str, Any]]:
+def update_signal_metrics(samples, sample_rate: int, offsets_hz, input_format: str = "cf32",
+                          shared_magnitudes: bool = False) -> list[dict[str, Any]]:
     """Channel.update_signal_metrics (capture.py:749-798) for all channels of one chunk in one pass:
     [{"rssi_db": float, "snr_db": float | None}] -- RSSI = 10 log10(mean |base|^2 + 1e-10); SNR from the
     10th / 90th percentile magnitudes exactly as np.partition picks them.  (The reference throttles the SNR
-    part to every 10th call; here it costs one extra select pass, so it is always returned.)"""
+    part to every 10th call; here it costs one extra select pass, so it is always returned.)
+
+    shared_magnitudes=True: the reference takes these statistics of `base = freq_shift(iq, offset)` BEFORE any
+    filtering, and a unit-magnitude mix leaves |base| = |iq| up to float32 rounding (1e-7 relative, 1e-6 dB on the
+    order statistics) -- so the chunk's magnitudes are ranked ONCE, without any mix, and every channel gets the same
+    numbers: K channels cost what one costs (the ChannelDispatcher's snr option uses this)."""
+    if shared_magnitudes:
+        one = update_signal_metrics(samples, sample_rate, [0.0], input_format)[0]
+        return [dict(one) for _ in offsets_hz]
     torch = _lib.require_gpu()
     if torch.is_tensor(samples):
         d = samples
@@ -554,7 +563,9 @@ class ChannelDispatcher:
         self.max_banks = int(max_banks)
         self._banks: dict[tuple, ChannelBank] = {}
 
-    def process(self, samples, cfgs) -> list[tuple[np.ndarray | None, dict[str, Any]]]:
+    def process(self, samples, cfgs, snr: bool = False) -> list[tuple[np.ndarray | None, dict[str, Any]]]:
+        """snr=True adds "snr_db" (Channel.update_signal_metrics, capture.py:776-796) to every channel's metrics from
+        ONE ranking of the uploaded chunk's magnitudes (no second mix pass, see update_signal_metrics)."""
         torch = self._torch
         cfgs = list(cfgs)
         if not cfgs:
@@ -590,8 +601,11 @@ class ChannelDispatcher:
                     bank = self._banks[bkey] = ChannelBank(self.sample_rate, n, [cfgs[i] for i in idx],
                                                            apply_squelch=self.apply_squelch)
                 launched.append((bank, idx, bank.process_device(d_in, 1)))    # all groups queued before any read-back
+            snr_db = update_signal_metrics(d_in, self.sample_rate, [0.0])[0]["snr_db"] if snr else None
             for bank, idx, (audio, met) in launched:
                 for i, r in zip(idx, bank.collect(audio, met)):
+                    if snr:
+                        r[1]["snr_db"] = snr_db
                     results[i] = r
         return results
 
