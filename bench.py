@@ -35,14 +35,50 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 BYTES_PER_SAMPLE = 24.0
 
 
-def cpu_baseline(seconds_budget: float = 12.0):
-    """Oracle (numpy port) timed on the host: PolyphaseChannelizer(10e6, 9765).process."""
-    import numpy as np
+def _cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+_CPU_X = None
+
+
+def _cpu_pfb_worker(args):
+    """One hop range of the oracle's channelizer on a shared input: the block holding the 8 hops of history before the
+    range is processed too (its rows are dropped), so every worker returns exactly its own rows."""
+    lo, hi, seed, n = args
     import signals as S
     from oracle import ref_np as O
 
+    x = _CPU_X if _CPU_X is not None and len(_CPU_X) == n else S.noise_c64(n, seed)   # shared with forked / threaded workers
+    ch = O.PolyphaseChannelizer(FS, BW)
+    h0 = max(0, lo - 8)
+    seg = x[h0 * 512: (hi - 1) * 512 + 1024]
+    t0 = time.perf_counter()
+    rows = ch.process(seg)
+    return len(rows) - (lo - h0), time.perf_counter() - t0
+
+
+def cpu_baseline(seconds_budget: float = 8.0):
+    """The oracle (numpy port of dsp/channelizer.py:91-137) timed on the host on a bounded sample, three ways (SURVEY.md
+    8(d)): 1 thread (the reference's channelizer is a single-threaded offline loop, benchmark_dsp.py:112-141);
+    ThreadPoolExecutor(3) over hop ranges (the pool size the reference's capture uses, capture.py:1918); os.cpu_count()
+    worker processes over hop ranges.  `value` / `cores` are the single-thread figure; the others ride along."""
+    import numpy as np
+    import signals as S
+    from concurrent.futures import ProcessPoolExecutor, ThreadPoolExecutor
+    from oracle import ref_np as O
+
+    global _CPU_X
+    import multiprocessing
+
     n = 1 << 21
-    x = S.noise_c64(n, 3)
+    x = _CPU_X = S.noise_c64(n, 3)
     ch = O.PolyphaseChannelizer(FS, BW)
     ch.process(x[: 1 << 16])
     ch.reset()
@@ -55,9 +91,48 @@ def cpu_baseline(seconds_budget: float = 12.0):
         if el > seconds_budget or reps >= 64:
             break
     msps = reps * n / el / 1e6
+    hops = (n - 1024) // 512 + 1
+    scaling = [{"cores": 1, "workers": "1 thread", "input_msps": round(msps, 2)}]
+
+    def ranges(k):
+        edges = [hops * i // k for i in range(k + 1)]
+        return [(edges[i], edges[i + 1], 3, n) for i in range(k) if edges[i + 1] > edges[i]]
+
+    try:
+        with ThreadPoolExecutor(3) as ex:                      # the reference's pool size, capture.py:1918
+            t1 = time.perf_counter()
+            got = sum(r[0] for r in ex.map(_cpu_pfb_worker, ranges(3)))
+            el3 = time.perf_counter() - t1
+        assert got == hops
+        scaling.append({"cores": 3, "workers": "ThreadPoolExecutor(3) over hop ranges", "input_msps": round(n / el3 / 1e6, 2)})
+        nc = os.cpu_count() or 1
+        with ProcessPoolExecutor(nc, mp_context=multiprocessing.get_context("fork")) as ex:   # forked before any GPU use
+            list(ex.map(_cpu_pfb_worker, ranges(nc)))          # start the workers (imports) outside the timed pass
+            t1 = time.perf_counter()
+            got = sum(r[0] for r in ex.map(_cpu_pfb_worker, ranges(nc)))
+            elc = time.perf_counter() - t1
+        assert got == hops
+        scaling.append({"cores": nc, "workers": f"{nc} processes over hop ranges (os.cpu_count())",
+                        "input_msps": round(n / elc / 1e6, 2)})
+    except Exception as e:      # the side measurements never take the bench line down
+        scaling.append({"error": f"{type(e).__name__}: {e}"})
     return {"value": round(msps * M, 1), "unit": "MS/s x channels", "cores": 1, "kind": "port",
             "sample": f"{reps} x 2^21 complex64 samples through oracle/ref_np.PolyphaseChannelizer "
-                      f"(M=1024, numpy {np.__version__}), {el:.1f} s", "input_msps": round(msps, 2)}
+                      f"(M=1024, numpy {np.__version__}), {el:.1f} s", "input_msps": round(msps, 2),
+            "cpu_model": _cpu_model(), "host_cores": os.cpu_count(), "scaling": scaling}
+
+
+def _profile_counter(kernel_substr: str, counter: str):
+    """Average of a hardware counter per launch of a kernel, from the committed rocprofv3 summary of this round
+    (profiles/r02_pmc_bench.json, written by tools/pmc_run.sh + tools/pmc_summary.py); None when absent."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_bench.json")))
+    except Exception:
+        return None
+    for name, rec in d.items():
+        if kernel_substr in name and counter in rec:
+            return float(rec[counter])
+    return None
 
 
 def secondary_nbfm(torch, steps: int = 5):
@@ -95,12 +170,64 @@ def secondary_nbfm(torch, steps: int = 5):
             "value": round(msps * K, 1), "unit": "MS/s x channels", "input_msps": round(msps, 1),
             "ms_per_launch": round(el * 1e3, 3), "x_realtime": round(msps / 2.4, 1),
             "algorithmic_GBps": round(6.56 * msps / 1e3, 2),
-            # the second roofline of this config ("report it against both"): VALU issue.  1.036e9 wave64
-            # VALU instructions per launch (profiles/r01_pmc_sq_nbfm.txt, SQ_INSTS_VALU of the shipped kernel), 4 cycles
-            # each on one of 1024 SIMDs at 2.4 GHz
-            "valu_issue_floor_ms": round(1.036e9 * 4 / 1024 / 2.4e9 * 1e3, 3),
-            "frac_of_valu_issue": round(1.036e9 * 4 / 1024 / 2.4e9 / el, 4),
+            **_nbfm_valu(el, chunks * n * K),
             "cpu_port_msps_x_channels": round(cpu, 2), "cpu_cores": 1}
+
+
+def _nbfm_valu(el: float, sample_channels: float):
+    """The second roofline of config 2 ("report it against both"): VALU issue.
+    Algorithmic floor: per sample x channel the chain needs the NCO phase (2 ops) + sin and cos (2 transcendentals, quarter
+    rate = 8 issue slots) + the mix (1 complex product, 2 packed ops) + the discriminator product (2 packed ops) + atan2
+    (1 reciprocal at quarter rate + ~8 polynomial ops = 12 slots) + 1001 taps / 50 = 20 real MACs per input sample
+    (10 packed FMAs) = 36 issue slots per lane, i.e. 36 / 64 wave64 instructions; a wave64 instruction holds one of the
+    1024 SIMDs for 4 cycles at <= 2.4 GHz.  Issue efficiency: SQ_INSTS_VALU of the shipped kernel, read from this round's
+    committed rocprofv3 summary (profiles/r02_pmc_bench.json), not a constant."""
+    slots = 36.0
+    floor = sample_channels * slots / 64.0 * 4.0 / 1024.0 / 2.4e9
+    out = {"algorithmic_valu_slots_per_sample_channel": slots, "algorithmic_valu_floor_ms": round(floor * 1e3, 3),
+           "frac_of_algorithmic_valu_floor": round(floor / el, 4)}
+    insts = _profile_counter("fmbank_fused_kernel", "SQ_INSTS_VALU")
+    if insts:
+        issue = insts * 4.0 / 1024.0 / 2.4e9
+        out.update({"sq_insts_valu_per_launch": insts, "valu_issue_floor_ms": round(issue * 1e3, 3),
+                    "frac_of_valu_issue": round(issue / el, 4)})
+    return out
+
+
+def _secondary_small_rows(torch):
+    """Rows whose kernels the verdict asked rocprof evidence for: spectrum (A8), Phase-2 CQPSK and LSM banks (A12).
+    Timings only; their kernel statistics come from the rocprofv3 summary of this same command (profiles/)."""
+    import wavehip
+
+    out = {}
+    N, frames = 2048, 16384
+    x = torch.view_as_complex(torch.randn(frames * N, 2, device="cuda") * 0.3)
+    be = wavehip.HipFFTBackend(N)
+    for _ in range(3):
+        be.execute_device(x, frames)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10):
+        be.execute_device(x, frames)
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / 10
+    out["spectrum"] = {"workload": "spectrum_kernel, 16384 frames of 2048 complex64 per call (12 B per sample: 8 in, 4 out)",
+                       "gsps": round(frames * N / el / 1e9, 1), "algorithmic_GBps": round(12.0 * frames * N / el / 1e9, 1),
+                       "frac_of_8TBps": round(12.0 * frames * N / el / 1e9 / HBM_PEAK_GBPS, 4)}
+    del x
+    for name, mk, fs in (("lsm_bank", lambda: wavehip.LSMBank(64, 19200, 4800, max_samples_per_call=19200), 19200),
+                         ("cqpsk_bank", lambda: wavehip.CQPSKBank(64, 48000, 12000, max_samples_per_call=48000), 48000)):
+        b = mk()
+        z = torch.view_as_complex(torch.randn(64, fs, 2, device="cuda").mul_(0.3))
+        for _ in range(2):
+            b.demodulate_device(z)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(3):
+            b.demodulate_device(z)
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / 3
+        out[name] = {"workload": f"64 channels x 1 s at {fs} S/s per call", "ms_per_call": round(el * 1e3, 2),
+                     "x_realtime_per_channel": round(1.0 / el, 1)}
+    return out
 
 
 def secondary_pfb_int16(torch, steps: int = 10):
@@ -129,7 +256,7 @@ def secondary_pfb_int16(torch, steps: int = 10):
 
 def secondary_pfb_m320(torch, steps: int = 5):
     """The channelizer shape of the reference's own benchmark_dsp.py:112-141 (8 MS/s, 25 kHz spacing -> M = 320,
-    pfb_run_kernel) beside the CPU oracle on the same shape."""
+    pfb_mid_kernel: 3 runs x 80 quads per 4-wave workgroup, one launch per call) beside the CPU oracle on the same shape."""
     import numpy as np
     import signals as S
     import wavehip
@@ -287,6 +414,8 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    # the CPU baseline forks worker processes: it runs first, before this process initialises the GPU
+    cpu_line = cpu_baseline() if (world == 1 and not args.no_cpu) else None
     assert torch.cuda.is_available(), "bench.py needs a ROCm GPU"
     # WH_BENCH_REHEARSAL=1: control-flow rehearsal of the N>1 path on a 1-GPU box (every rank on
     # cuda:0, gloo instead of RCCL for the tiny stats exchange).  Never set by the driver.
@@ -385,7 +514,7 @@ def main() -> None:
         fused_samples = ((hops - 8) // 4) * 4 * 512           # samples consumed by the fused kernel's hops
         achieved = BYTES_PER_SAMPLE * fused_samples / (k_ms * 1e-3) / 1e9
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")   # written by tools/pmc_to_profiles.py from this round's passes
         if os.path.exists(pmc):
             try:
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
@@ -400,7 +529,7 @@ def main() -> None:
                                    f"2^{args.log2n} samples per step per GPU, one stream per GPU "
                                    "(BASELINE.json configs[2] / configs[4])",
                        "samples_per_step_per_gpu": n, "hops_per_step": hops, "channels": M,
-                       "scan_window_hops": scan, "collective": "rccl all_gather(stats 40 KB/GPU), async, 1 per step" if world > 1 else "none",
+                       "scan_window_hops": scan, "collective": (f"{dist.get_backend()} all_gather(stats 40 KB/GPU), " + ("async, 1 per step" if reducer is not None else "synchronous all-reduces (rehearsal)")) if world > 1 else "none",
                        "scanner_reduce_ms": None if reduce_ms is None else round(reduce_ms, 4)},
             "input_msps": round(world * n * args.steps / elapsed / 1e6, 1),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -439,15 +568,16 @@ def main() -> None:
             line["roofline"]["stream_1r2w_yardstick_GBps"] = round(sy, 1)
             line["roofline"]["frac_of_stream_yardstick"] = round(line["roofline"]["achieved"] / sy, 4)
             del ys
-        if world == 1 and not args.no_cpu:
-            line["cpu_baseline"] = cpu_baseline()
+        if cpu_line is not None:
+            line["cpu_baseline"] = cpu_line
         if world == 1 and not args.no_secondary:
             del x, out
             torch.cuda.empty_cache()
             line["secondary"] = {"pfb_int16": secondary_pfb_int16(torch), "pfb_m320": secondary_pfb_m320(torch),
                                  "wbfm_single": secondary_wbfm(torch),
                                  "nbfm_bank": secondary_nbfm(torch),
-                                 "c4fm_bank": secondary_c4fm(torch), "ddc_bank": secondary_ddc(torch)}
+                                 "c4fm_bank": secondary_c4fm(torch), "ddc_bank": secondary_ddc(torch),
+                                 **_secondary_small_rows(torch)}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -5,7 +5,7 @@ set -e
 OUT=$1; shift; shift
 export TMPDIR=/tmp
 mkdir -p "$OUT"
-rocprofv3 --kernel-trace --stats -d "$OUT/trace" --output-format csv -- "$@" > "$OUT/trace.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$OUT/trace" --output-format csv -- "$@" ${TRACE_EXTRA} > "$OUT/trace.log" 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT -d "$OUT/sq1" --output-format csv -- "$@" > "$OUT/sq1.log" 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS -d "$OUT/sq2" --output-format csv -- "$@" > "$OUT/sq2.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE -d "$OUT/fetch" --output-format csv -- "$@" > "$OUT/fetch.log" 2>&1

@@ -38,7 +38,7 @@ for k in sorted(set(cnt) | set(dur)):
     if dur[k]:
         v = dur[k]
         print(f"    dispatches {len(v)}  avg {sum(v)/len(v):.2f} us  min {min(v):.2f}  max {max(v):.2f}")
-        o["avg_us"], o["n"] = sum(v) / len(v), len(v)
+        o["avg_us"], o["n"], o["min_us"], o["max_us"] = sum(v) / len(v), len(v), min(v), max(v)
     wc = None
     if "SQ_WAVE_CYCLES" in cnt[k]:
         vals = list(cnt[k]["SQ_WAVE_CYCLES"].values()); wc = sum(vals) / len(vals)
