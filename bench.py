@@ -396,6 +396,32 @@ def secondary_c4fm(torch, steps: int = 2):
             "cpu_port_x_realtime_per_channel": round(C * secs / cpu_s, 1), "cpu_cores": 1}
 
 
+def drive(step, reducer, steps: int, warmup: int, prewarm: int, sync, barrier, after_step=None):
+    """The bench's control flow, shared by every rank: `prewarm` + `warmup` untimed steps, then EXACTLY `steps` timed
+    ones bracketed by barrier + synchronize on both sides; the last scan's exchange is collected inside the timed
+    region.  Every rank runs the same number of steps, so the one collective per step (reducer.submit inside `step`)
+    stays matched across ranks -- tests/test_multi_gpu_cpu.py runs this on two gloo ranks.  Returns (elapsed seconds on
+    this rank, merged statistics of the last scan or None)."""
+    for _ in range(prewarm):
+        step()
+    sync()
+    for _ in range(warmup):
+        step()
+    sync()
+    barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+        if after_step is not None:
+            after_step()
+    last = reducer.wait(merge=True) if reducer is not None else None
+    sync()
+    barrier()
+    sync()
+    return time.perf_counter() - t0, last
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -462,28 +488,13 @@ def main() -> None:
     # untimed pre-warm (a FIXED 200 steps ~ 0.3 s, identical on every rank so the collectives stay
     # matched) so the W warmup + K timed steps run at the clocks the chip holds under sustained
     # load rather than on the DVFS ramp of a cold device
-    for _ in range(200):
-        step()
-    torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
     kernel_ms = []
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        kernel_ms.append(ch.last_kernel_ms())      # waits for that step's fused kernel only
+    elapsed, last = drive(step, reducer, args.steps, args.warmup, 200, torch.cuda.synchronize,
+                          dist.barrier if world > 1 else (lambda: None),
+                          after_step=lambda: kernel_ms.append(ch.last_kernel_ms()))   # waits for that step's fused kernel only
     if reducer is not None:
-        last = reducer.wait(merge=True)     # the last scan's exchange + merge are inside the timed region
         assert last is not None and last.shape == (M, 5)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+        assert reducer.submitted == 200 + args.warmup + args.steps
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -190,6 +190,13 @@ int wh_pfb_extract_channel(const float *d_out, size_t hops, int channel_count, i
 int wh_pfb_channel_stats(wh_pfb *p, const float *d_out, size_t hops, double *d_stats, int accumulate,
                          void *stream);
 
+/* Cross-stream merge of the activity statistics (cc_scanner.py:355-400 / channel_classifier.py:17-48
+ * across device streams): d_gathered float64 [n_ranks][n_channels][5] -- the blocks wh_pfb_channel_stats wrote on every
+ * GPU, brought together by ONE all-gather (RCCL ncclAllGather on these caller-owned buffers, or torch.distributed) --
+ * -> d_out [n_channels][5] = {sum, sum, sum, min, max} in fixed rank order (identical bits on every rank).  The library
+ * itself makes no collective call: the communicator belongs to the host program. */
+int wh_stats_merge(const double *d_gathered, int n_ranks, int n_channels, double *d_out, void *stream);
+
 /* Diagnostics (no reference counterpart): the filterbank's HBM traffic shape with no arithmetic -- reads n complex64
  * from d_in, writes them twice (2n complex64) to d_out; n even.  bench.py times it beside the filterbank as the
  * in-process yardstick for a 1 : 2 read : write stream. */

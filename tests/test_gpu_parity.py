@@ -964,6 +964,22 @@ def test_a7_pfb_prefetch_forms_agree(wh):
     assert all(torch.equal(ref, o) for v in outs for o in outs[v])
 
 
+def test_a13_stats_merge_kernel(wh):
+    """wh_stats_merge (the device half of the cross-stream activity reduction: gathered [ranks][M][5] -> [M][5]) equals the
+    host merge of scanner_reduce bit for bit, for 1, 2 and 8 ranks."""
+    import torch
+    from wavehip.scanner_reduce import AsyncStatsReducer
+
+    g = torch.Generator(device="cuda").manual_seed(9)
+    for R in (1, 2, 8):
+        x = torch.rand((R, 1024, 5), dtype=torch.float64, device="cuda", generator=g) * 1e3
+        dev = AsyncStatsReducer.merge_gathered(x)
+        host = AsyncStatsReducer.merge_gathered(x.cpu())
+        # fixed rank order on the device; torch's host sum over dim 0 adds in the same order for these sizes
+        assert dev.shape == (1024, 5) and torch.allclose(dev.cpu(), host, rtol=1e-15, atol=0)
+        assert torch.equal(dev[:, 3].cpu(), host[:, 3]) and torch.equal(dev[:, 4].cpu(), host[:, 4])
+
+
 def test_diag_stream_yardstick_copies_twice(wh):
     """wh_diag_stream_1r2w (the no-arithmetic traffic yardstick bench.py times beside the filterbank) really moves the
     bytes it is credited with: the input appears twice in the output, ragged length included; odd n is refused."""

@@ -785,6 +785,20 @@ __global__ __launch_bounds__(256) void pfb_stats_final_kernel(const double *part
     }
 }
 
+// merged[c] = {sum_r s0, sum_r s1, sum_r s2, min_r s3, max_r s4} over the gathered rows [R][M][5], ranks in order
+__global__ void stats_merge_kernel(const double *g, int R, int M, double *out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= M) return;
+    double s0 = 0, s1 = 0, s2 = 0, mn = 1e300, mx = -1e300;
+    for (int r = 0; r < R; ++r) {
+        const double *p = g + ((size_t)r * M + c) * 5;
+        s0 += p[0]; s1 += p[1]; s2 += p[2];
+        mn = fmin(mn, p[3]); mx = fmax(mx, p[4]);
+    }
+    double *o = out + (size_t)c * 5;
+    o[0] = s0; o[1] = s1; o[2] = s2; o[3] = mn; o[4] = mx;
+}
+
 }  // namespace
 
 struct wh_pfb {
@@ -1177,6 +1191,14 @@ extern "C" int wh_diag_stream_1r2w(const float *d_in, float *d_out, size_t n, vo
     if (mode == 1) hipLaunchKernelGGL(stream_1r2w_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), in4, out4, n4);
     else if (mode == 2) hipLaunchKernelGGL(stream_1r2w_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), in4, out4, n4);
     else hipLaunchKernelGGL(stream_1r2w_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), in4, out4, n4);
+    WH_LAUNCH_CHECK();
+    return WH_OK;
+}
+
+extern "C" int wh_stats_merge(const double *d_gathered, int n_ranks, int n_channels, double *d_out, void *stream) {
+    if (!d_gathered || !d_out || n_ranks < 1 || n_channels < 1) return set_err(WH_E_ARG, "wh_stats_merge: bad arguments");
+    hipLaunchKernelGGL(stats_merge_kernel, dim3((n_channels + 255) / 256), dim3(256), 0, as_stream(stream), d_gathered,
+                       n_ranks, n_channels, d_out);
     WH_LAUNCH_CHECK();
     return WH_OK;
 }

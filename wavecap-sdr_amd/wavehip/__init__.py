@@ -18,6 +18,7 @@ from .fft_backend import HipFFTBackend, FFTResult, FFTBackend, is_available, reg
 from .channel_ops import (ChannelBank, ChannelConfig, ChannelDispatcher, process_channel_dsp_stateless,  # noqa: F401
                           update_signal_metrics, noise_blanker)
 from .capture_seam import process_channels_parallel  # noqa: F401
+from . import channel_split  # noqa: F401
 from .wire import pack_iq16, unpack_iq16, pack_pcm16, pack_f32  # noqa: F401
 from .framer import P25P1SoftSyncDetector, SoftSyncBank, P25NIDFrontEnd, NACTracker  # noqa: F401
 from .fec import BCHDecoder, bch_decode  # noqa: F401

@@ -28,13 +28,19 @@ def reduce_channel_stats(stats, group=None):
 
 class AsyncStatsReducer:
     """One collective per scan instead of three, overlapped with the next compute step:
-    `submit(stats)` all-gathers the packed [M, 5] block asynchronously (RCCL runs it on its own
-    stream after the producing kernel), `result()` waits and merges sum / min / max locally.
-    Double-buffered so a scan can be in flight while the next one is produced."""
+    `submit(stats)` copies the packed [M, 5] block into a reducer-owned ping-pong buffer and all-gathers it
+    asynchronously (RCCL runs it on its own stream after the producing kernel; the caller may overwrite `stats`
+    right away), `wait()` blocks the current stream on it and merges sum / min / max (on the GPU by the
+    wh_stats_merge kernel).  One scan can be in flight while the next one is produced; every rank must call
+    submit() / wait() the same number of times (each submit is one collective)."""
 
     def __init__(self, group=None):
         self.group = group
         self._pending = None      # (work, gathered tensor)
+        self._send = [None, None]   # ping-pong copies of the submitted block (the collective reads them asynchronously)
+        self._recv = [None, None]
+        self._k = 0
+        self.submitted = 0
 
     def submit(self, stats):
         import torch
@@ -42,14 +48,22 @@ class AsyncStatsReducer:
 
         self.wait()
         world = dist.get_world_size(self.group)
-        out = torch.empty((world * stats.shape[0],) + tuple(stats.shape[1:]), dtype=stats.dtype, device=stats.device)
-        work = dist.all_gather_into_tensor(out, stats.contiguous(), group=self.group, async_op=True)
-        self._pending = (work, out.view((world,) + tuple(stats.shape)))
+        k = self._k
+        self._k ^= 1
+        if self._send[k] is None or self._send[k].shape != stats.shape or self._send[k].device != stats.device:
+            self._send[k] = torch.empty_like(stats, memory_format=torch.contiguous_format)
+            self._recv[k] = torch.empty((world * stats.shape[0],) + tuple(stats.shape[1:]), dtype=stats.dtype,
+                                        device=stats.device)
+        self._send[k].copy_(stats)
+        work = dist.all_gather_into_tensor(self._recv[k], self._send[k], group=self.group, async_op=True)
+        self._pending = (work, self._recv[k].view((world,) + tuple(stats.shape)))
+        self.submitted += 1
 
     def wait(self, merge: bool = True):
         """Block the CURRENT stream on the pending collective (no host sync).  Returns the merged
         [M, 5] view, or with merge=False the raw gathered [world, M, 5] block (merge it later with
-        `merge_gathered`, e.g. once per scan interval instead of once per pass)."""
+        `merge_gathered`, e.g. once per scan interval instead of once per pass; it aliases a reducer buffer that the
+        second next submit() overwrites)."""
         if self._pending is None:
             return None
         work, out = self._pending
@@ -59,8 +73,18 @@ class AsyncStatsReducer:
 
     @staticmethod
     def merge_gathered(out):
+        """[world, M, 5] -> [M, 5]: sums of {sum p, sum p^2, count}, min, max.  On the GPU: the wh_stats_merge kernel
+        (fixed rank order, so every rank computes the same bits); host tensors (the gloo tests) are merged here."""
         import torch
 
+        if out.is_cuda and out.dtype == torch.float64 and out.shape[2] == 5:
+            from . import _lib
+
+            o = out.contiguous()
+            res = torch.empty(o.shape[1:], dtype=torch.float64, device=o.device)
+            _lib.check(_lib.lib.wh_stats_merge(o.data_ptr(), o.shape[0], o.shape[1], res.data_ptr(), _lib.stream_ptr(torch)),
+                       "wh_stats_merge")
+            return res
         return torch.cat([out[:, :, 0:3].sum(0), out[:, :, 3].min(0).values[:, None],
                           out[:, :, 4].max(0).values[:, None]], dim=1)
 
