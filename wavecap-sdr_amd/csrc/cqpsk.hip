@@ -4,9 +4,11 @@
 // (symbol_timing.py:60-211).  The reference computes all of it in Python float / complex128.
 //   k_cq_rrc   matched filter, complex128, one thread per output of the full convolution
 //              (the reference re-seeds lfilter with zi = state * iq[0] on every call -- kept);
-//   k_cq_seq   ONE LANE PER CHANNEL: the Costas PLL feeds back every sample, so the loop is
-//              sequential in time; a bank of channels fills the wavefronts.  Float64 with
-//              explicit *_rn ops in the order of oracle/cqpsk_ref.c (no FMA contraction);
+//   k_cq_seq   ONE WAVE PER CHANNEL: the Costas PLL feeds back every sample, so the loop is
+//              sequential in time and its speed is the latency of one dependent float64 chain;
+//              channels spread over the SIMDs (see the kernel).  Float64, the loop equations with
+//              explicit *_rn ops in the order of oracle/cqpsk_ref.c; sincos / atan2 by short
+//              polynomial chains (1e-15), distances compared squared;
 //   k_gardner  Gardner TED bank, one lane per channel, float64, bit-exact vs the oracle.
 #include "wh_common.h"
 #include <cmath>
@@ -82,79 +84,167 @@ __device__ __forceinline__ double interp1(double v0, double v1, double v2, doubl
     return DA(c0, DM(mu, DA(c1, DM(mu, DA(c2, DM(mu, c3))))));
 }
 
+// ---- float64 elementary functions for the feedback loop: accuracy ~1e-15 (the parity bar on the symbols is 1e-9), built
+// for a SHORT DEPENDENT CHAIN -- the loop below is one wave walking one channel sample by sample, so its time is the
+// latency of this chain, not instruction throughput (library sincos / atan2 are 3-5x deeper, with slow paths and scratch).
+
+// sin and cos of x in [-pi, pi] (the Costas phase is wrapped every sample): quadrant reduction by pi/2 in two parts, then
+// the fdlibm kernels on [-pi/4, pi/4], Horner in fused multiply-adds; the two chains are independent (ILP 2)
+__device__ __forceinline__ void cq_sincos(double x, double &sn, double &cs) {
+    const double k = rint(x * 0.63661977236758134308);
+    double r = fma(-k, 1.57079632673412561417e+00, x);
+    r = fma(-k, 6.07710050650619224932e-11, r);
+    const double z = r * r;
+    double sp = 1.58969099521155010221e-10;
+    sp = fma(sp, z, -2.50507602534068634195e-08);
+    sp = fma(sp, z, 2.75573137070700676789e-06);
+    sp = fma(sp, z, -1.98412698298579493134e-04);
+    sp = fma(sp, z, 8.33333333332248946124e-03);
+    sp = fma(sp, z, -1.66666666666666324348e-01);
+    const double s = fma(r * z, sp, r);
+    double cp = -1.13596475577881948265e-11;
+    cp = fma(cp, z, 2.08757232129817482790e-09);
+    cp = fma(cp, z, -2.75573143513906633035e-07);
+    cp = fma(cp, z, 2.48015872894767294178e-05);
+    cp = fma(cp, z, -1.38888888888741095749e-03);
+    cp = fma(cp, z, 4.16666666666666019037e-02);
+    const double c = fma(z * z, cp, fma(-0.5, z, 1.0));
+    const int q = (int)k & 3;
+    sn = q == 0 ? s : q == 1 ? c : q == 2 ? -s : -c;
+    cs = q == 0 ? c : q == 1 ? -s : q == 2 ? -c : s;
+}
+
+// atan(t) / t = g(t^2) on t in [0, 1]: degree-17 interpolant (tools/gen_atan_coeffs.py, max error 1.1e-15), Estrin scheme
+__device__ __forceinline__ double cq_atan_g(double z) {
+    const double z2 = z * z, z4 = z2 * z2, z8 = z4 * z4;
+    const double p0 = fma(-3.33333333332591741e-01, z, 9.99999999999999001e-01);
+    const double p1 = fma(-1.42857139184933563e-01, z, 1.99999999916576798e-01);
+    const double p2 = fma(-9.09078887746185699e-02, z, 1.11111026064682761e-01);
+    const double p3 = fma(-6.65914387633817773e-02, z, 7.69117547592351042e-02);
+    const double p4 = fma(-5.12804947274475356e-02, z, 5.84566961719584707e-02);
+    const double p5 = fma(-3.48821635173907907e-02, z, 4.37765634493981481e-02);
+    const double p6 = fma(-1.44677131781058912e-02, z, 2.45987495873041459e-02);
+    const double p7 = fma(-2.20104195614385977e-03, z, 6.64853643130743337e-03);
+    const double p8 = fma(-4.58125276638879266e-05, z, 4.61862979263086531e-04);
+    const double q0 = fma(p1, z2, p0), q1 = fma(p3, z2, p2), q2 = fma(p5, z2, p4), q3 = fma(p7, z2, p6);
+    const double r0 = fma(q1, z4, q0), r1 = fma(q3, z4, q2);
+    return fma(fma(p8, z8, r1), z8, r0);     // r0 + z^8 (r1 + z^8 p8)
+}
+
+__device__ __forceinline__ double cq_atan2(double y, double x) {
+    const double ax = fabs(x), ay = fabs(y);
+    const double mx = fmax(ax, ay), mn = fmin(ax, ay);
+    double r = __builtin_amdgcn_rcp(mx);             // ~2^-26 relative; two Newton steps -> full precision
+    r = fma(fma(-mx, r, 1.0), r, r);
+    r = fma(fma(-mx, r, 1.0), r, r);
+    const double t = mx > 0.0 ? mn * r : 0.0;        // atan2(0, 0) = 0
+    double a = t * cq_atan_g(t * t);
+    a = ay > ax ? 1.5707963267948966 - a : a;
+    a = x < 0.0 ? PI_D - a : a;
+    return copysign(a, y);
+}
+
+// ONE WAVE PER CHANNEL, every lane running the same scalar loop (uniform control flow: the symbol branch costs a wave only
+// when ITS channel has a symbol; with one lane per channel every wave paid for it on every sample).  The loop is a
+// dependent float64 chain (Costas phase -> sincos -> rotate -> atan2 -> error -> phase), so a channel's time is latency
+// bound and channels scale across the 1024 SIMDs, not across lanes.  Input: the wave loads 64 samples at a time with one
+// coalesced 1 KiB read and hands them out by readlane.
 __global__ __launch_bounds__(64) void k_cq_seq(CqArgs a) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= a.C) return;
-    CqState s = a.st[c];
+    const int c = blockIdx.x, lane = threadIdx.x;
+    CqState *const sp = a.st + c;
+    // (field by field: a whole-struct copy of the state, with its buf[4] array, lands in scratch)
+    struct { double c_phase, c_freq, t_phase, t_integ, prev_phase; double2 prev_sym, prev_dec; } s;
+    s.c_phase = sp->c_phase; s.c_freq = sp->c_freq; s.t_phase = sp->t_phase; s.t_integ = sp->t_integ;
+    s.prev_phase = sp->prev_phase; s.prev_sym = sp->prev_sym; s.prev_dec = sp->prev_dec;
+    const double2 sb0 = sp->buf[0], sb1 = sp->buf[1], sb2 = sp->buf[2], sb3 = sp->buf[3];
     const double2 *full = a.full + (size_t)c * (a.n_max + a.L - 1);
     uint8_t *dib = a.dibits + (size_t)c * a.cap;
     double2 *sym = a.symbols ? a.symbols + (size_t)c * a.cap : nullptr;
-    const double q = PI_D / 4;
-    const double inv = 1.4142135623730951;
-    // the 4-entry circular buffer lives in registers: keep it rotated so that b3 is the newest
-    double2 b0 = s.buf[(s.buf_idx + 1) & 3], b1 = s.buf[(s.buf_idx + 2) & 3], b2 = s.buf[(s.buf_idx + 3) & 3],
-            b3 = s.buf[s.buf_idx & 3];
+    const double q = PI_D / 4, inv_q = 1.0 / (PI_D / 4);
+    const double inv_sps = 1.0 / a.sps;
+    const double R2 = 0.70710678118654746;   // 1 / 1.4142135623730951 as the reference computes it (kr / inv)
+    // the 4-entry circular buffer lives in registers, rotated so that b3 is the newest (no dynamic indexing: scratch)
+    const int bi = sp->buf_idx & 3;
+    double2 b0 = bi == 0 ? sb1 : bi == 1 ? sb2 : bi == 2 ? sb3 : sb0;
+    double2 b1 = bi == 0 ? sb2 : bi == 1 ? sb3 : bi == 2 ? sb0 : sb1;
+    double2 b2 = bi == 0 ? sb3 : bi == 1 ? sb0 : bi == 2 ? sb1 : sb2;
+    double2 b3 = bi == 0 ? sb0 : bi == 1 ? sb1 : bi == 2 ? sb2 : sb3;
     int count = 0;
-    for (int t = 0; t < a.n; ++t) {
-        double2 x = full[t];
-        double sn, cs;
-        sincos(s.c_phase, &sn, &cs);
-        double cr = DS(DM(x.x, cs), DM(x.y, -sn));
-        double ci = DA(DM(x.x, -sn), DM(x.y, cs));
-        double ph = atan2(ci, cr);
-        double ideal = DM(rint(DD(ph, q)), q);
-        double err = DS(ph, ideal);
-        while (err > PI_D) err = DS(err, 2 * PI_D);
-        while (err < -PI_D) err = DA(err, 2 * PI_D);
-        s.c_freq = DA(s.c_freq, DM(a.c_ki, err));
-        if (s.c_freq < -a.c_maxf) s.c_freq = -a.c_maxf;
-        if (s.c_freq > a.c_maxf) s.c_freq = a.c_maxf;
-        s.c_phase = DA(s.c_phase, DA(DM(a.c_kp, err), s.c_freq));
-        while (s.c_phase > PI_D) s.c_phase = DS(s.c_phase, 2 * PI_D);
-        while (s.c_phase < -PI_D) s.c_phase = DA(s.c_phase, 2 * PI_D);
-        b0 = b1; b1 = b2; b2 = b3; b3 = make_double2(cr, ci);
-        s.t_phase = DA(s.t_phase, 1.0);
-        if (s.t_phase >= a.sps) {
-            s.t_phase = DS(s.t_phase, a.sps);
-            double mu = DD(s.t_phase, a.sps);
-            double sr = interp1(b0.x, b1.x, b2.x, b3.x, mu);
-            double si = interp1(b0.y, b1.y, b2.y, b3.y, mu);
-            int best = 0;
-            double bd = 0.0;
+    for (int t0 = 0; t0 < a.n; t0 += 64) {
+        const double2 xl = t0 + lane < a.n ? full[t0 + lane] : make_double2(0.0, 0.0);
+        const int m = a.n - t0 < 64 ? a.n - t0 : 64;
+        for (int j = 0; j < m; ++j) {
+            double2 x;
+            {
+                const int xlo = __builtin_amdgcn_readlane(__double2loint(xl.x), j), xhi = __builtin_amdgcn_readlane(__double2hiint(xl.x), j);
+                const int ylo = __builtin_amdgcn_readlane(__double2loint(xl.y), j), yhi = __builtin_amdgcn_readlane(__double2hiint(xl.y), j);
+                x = make_double2(__hiloint2double(xhi, xlo), __hiloint2double(yhi, ylo));
+            }
+            double sn, cs;
+            cq_sincos(s.c_phase, sn, cs);
+            double cr = DS(DM(x.x, cs), DM(x.y, -sn));
+            double ci = DA(DM(x.x, -sn), DM(x.y, cs));
+            double ph = cq_atan2(ci, cr);
+            double ideal = DM(rint(DM(ph, inv_q)), q);
+            double err = DS(ph, ideal);
+            err = err > PI_D ? DS(err, 2 * PI_D) : err;
+            err = err < -PI_D ? DA(err, 2 * PI_D) : err;
+            s.c_freq = DA(s.c_freq, DM(a.c_ki, err));
+            s.c_freq = fmin(fmax(s.c_freq, -a.c_maxf), a.c_maxf);
+            s.c_phase = DA(s.c_phase, DA(DM(a.c_kp, err), s.c_freq));
+            while (s.c_phase > PI_D) s.c_phase = DS(s.c_phase, 2 * PI_D);
+            while (s.c_phase < -PI_D) s.c_phase = DA(s.c_phase, 2 * PI_D);
+            b0 = b1; b1 = b2; b2 = b3; b3 = make_double2(cr, ci);
+            s.t_phase = DA(s.t_phase, 1.0);
+            if (s.t_phase >= a.sps) {
+                s.t_phase = DS(s.t_phase, a.sps);
+                double mu = DM(s.t_phase, inv_sps);
+                double sr = interp1(b0.x, b1.x, b2.x, b3.x, mu);
+                double si = interp1(b0.y, b1.y, b2.y, b3.y, mu);
+                // nearest constellation point (+-1 +-i) / sqrt 2, first minimum in the reference's order k = 0..3; the
+                // squared distances order like the reference's hypot()s
+                int best = 0;
+                double bd = 0.0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                double kr = (k == 0 || k == 3) ? 1.0 : -1.0, ki = (k < 2) ? 1.0 : -1.0;
-                double d = hypot(DS(DD(kr, inv), sr), DS(DD(ki, inv), si));
-                if (k == 0 || d < bd) { bd = d; best = k; }
+                for (int k = 0; k < 4; ++k) {
+                    const double kr = (k == 0 || k == 3) ? R2 : -R2, ki = (k < 2) ? R2 : -R2;
+                    const double dx = DS(kr, sr), dy = DS(ki, si);
+                    const double d = fma(dx, dx, dy * dy);
+                    if (k == 0 || d < bd) { bd = d; best = k; }
+                }
+                double dr = (best == 0 || best == 3) ? R2 : -R2, di = best < 2 ? R2 : -R2;
+                double e1 = DS(DM(s.prev_dec.x, sr), DM(-s.prev_dec.y, si));
+                double e2 = DS(DM(dr, s.prev_sym.x), DM(-di, s.prev_sym.y));
+                double e = DS(e1, e2);
+                s.t_integ = DA(s.t_integ, DM(a.t_ki, e));
+                s.t_integ = fmin(fmax(s.t_integ, -a.t_maxdev), a.t_maxdev);
+                s.t_phase = DA(s.t_phase, DA(DM(a.t_kp, e), s.t_integ));
+                s.prev_sym = make_double2(sr, si);
+                s.prev_dec = make_double2(dr, di);
+                double p = cq_atan2(si, sr);
+                double dp = DS(p, s.prev_phase);
+                dp = dp > PI_D ? DS(dp, 2 * PI_D) : dp;
+                dp = dp < -PI_D ? DA(dp, 2 * PI_D) : dp;
+                long long idx = (long long)rint(DM(DA(dp, PI_D), inv_q));
+                idx = ((idx % 8) + 8) % 8;
+                if ((size_t)count < a.cap) {
+                    if (lane == 0) {
+                        dib[count] = (uint8_t)(idx >> 1);
+                        if (sym) sym[count] = make_double2(sr, si);
+                    }
+                    count++;
+                }
+                s.prev_phase = p;
             }
-            double dr = DD((best == 0 || best == 3) ? 1.0 : -1.0, inv), di = DD(best < 2 ? 1.0 : -1.0, inv);
-            double e1 = DS(DM(s.prev_dec.x, sr), DM(-s.prev_dec.y, si));
-            double e2 = DS(DM(dr, s.prev_sym.x), DM(-di, s.prev_sym.y));
-            double e = DS(e1, e2);
-            s.t_integ = DA(s.t_integ, DM(a.t_ki, e));
-            if (s.t_integ < -a.t_maxdev) s.t_integ = -a.t_maxdev;
-            if (s.t_integ > a.t_maxdev) s.t_integ = a.t_maxdev;
-            s.t_phase = DA(s.t_phase, DA(DM(a.t_kp, e), s.t_integ));
-            s.prev_sym = make_double2(sr, si);
-            s.prev_dec = make_double2(dr, di);
-            double p = atan2(si, sr);
-            double dp = DS(p, s.prev_phase);
-            while (dp > PI_D) dp = DS(dp, 2 * PI_D);
-            while (dp < -PI_D) dp = DA(dp, 2 * PI_D);
-            long long idx = (long long)rint(DD(DA(dp, PI_D), q));
-            idx = ((idx % 8) + 8) % 8;
-            if ((size_t)count < a.cap) {
-                dib[count] = (uint8_t)(idx >> 1);
-                if (sym) sym[count] = make_double2(sr, si);
-                count++;
-            }
-            s.prev_phase = p;
         }
     }
-    s.buf[0] = b0; s.buf[1] = b1; s.buf[2] = b2; s.buf[3] = b3;
-    s.buf_idx = 3;
-    a.st[c] = s;
-    a.counts[c] = count;
+    if (lane == 0) {
+        sp->c_phase = s.c_phase; sp->c_freq = s.c_freq; sp->t_phase = s.t_phase; sp->t_integ = s.t_integ;
+        sp->prev_phase = s.prev_phase; sp->prev_sym = s.prev_sym; sp->prev_dec = s.prev_dec;
+        sp->buf[0] = b0; sp->buf[1] = b1; sp->buf[2] = b2; sp->buf[3] = b3;
+        sp->buf_idx = 3;
+        a.counts[c] = count;
+    }
 }
 
 struct GState {
@@ -284,7 +374,7 @@ extern "C" int wh_cqpsk_bank_run(wh_cqpsk_bank *b, const float *d_iq, size_t n, 
     const int H = b->L - 1;
     hipLaunchKernelGGL(k_cq_rrc, dim3((unsigned)((n + H + 255) / 256), b->C), dim3(256), b->L * sizeof(double), st, a);
     WH_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_cq_seq, dim3((b->C + 63) / 64), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_cq_seq, dim3((unsigned)b->C), dim3(64), 0, st, a);   // one wave per channel
     WH_LAUNCH_CHECK();
     b->cur ^= 1;
     return WH_OK;
