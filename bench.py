@@ -254,6 +254,45 @@ def secondary_pfb_int16(torch, steps: int = 10):
             "frac_of_8TBps": round(20.0 * n / k / 1e6 / 8000.0, 4)}
 
 
+def secondary_pfb_stats(torch, steps: int = 10):
+    """The scanner's real workload (A13 / config 5): the 1024-channel filterbank in statistics-only mode -- per-channel
+    {sum, sum of squares, min, max} of |y|^2 reduced in the last FFT pass, no channel outputs written: 8 algorithmic bytes
+    per input sample (the read).  The arithmetic is unchanged, so this form is bound by VALU / LDS, not by HBM."""
+    import wavehip
+
+    n = 1 << 28
+    ch = wavehip.PolyphaseChannelizer(FS, BW)
+    x = torch.view_as_complex(torch.randn(n, 2, device="cuda").mul_(0.5))
+    stats = torch.zeros((M, 5), dtype=torch.float64, device="cuda")
+    for _ in range(5):
+        ch.process_stats_device(x, stats)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ch.process_stats_device(x, stats)
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / steps
+    # the same statistics the long way: full output, then wh_pfb_channel_stats over ALL its hops
+    out = torch.empty((ch.hops(n), M), dtype=torch.complex64, device="cuda")
+    full = wavehip.PolyphaseChannelizer(FS, BW)
+    for _ in range(3):
+        full.channel_stats_device(full.process_device(x, out), stats)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        full.channel_stats_device(full.process_device(x, out), stats)
+    torch.cuda.synchronize()
+    el2 = (time.perf_counter() - t0) / steps
+    return {"workload": "1024-channel filterbank, statistics only (no channel outputs), 2^28 complex64 samples per call",
+            "ms_per_call": round(el * 1e3, 4), "input_msps": round(n / el / 1e6, 1),
+            "algorithmic_GBps": round(8.0 * n / el / 1e9, 1), "frac_of_8TBps": round(8.0 * n / el / 1e9 / HBM_PEAK_GBPS, 4),
+            "ms_full_output_plus_stats_over_all_hops": round(el2 * 1e3, 4), "speedup_vs_that": round(el2 / el, 3),
+            "speedup_vs_full_output_pass": None,
+            "note": "VALU-bound: the float64 statistics add ~8 half-rate instructions per output to a kernel that is no longer "
+                    "waiting for its stores; it wins over output + a statistics pass over all hops and frees the 4.3 GB output "
+                    "buffer, not over the bare output pass"}
+
+
 def secondary_pfb_m320(torch, steps: int = 5):
     """The channelizer shape of the reference's own benchmark_dsp.py:112-141 (8 MS/s, 25 kHz spacing -> M = 320,
     pfb_mid_kernel: 3 runs x 80 quads per 4-wave workgroup, one launch per call) beside the CPU oracle on the same shape."""
@@ -584,11 +623,15 @@ def main() -> None:
         if world == 1 and not args.no_secondary:
             del x, out
             torch.cuda.empty_cache()
-            line["secondary"] = {"pfb_int16": secondary_pfb_int16(torch), "pfb_m320": secondary_pfb_m320(torch),
+            line["secondary"] = {"pfb_int16": secondary_pfb_int16(torch), "pfb_stats_only": secondary_pfb_stats(torch),
+                                 "pfb_m320": secondary_pfb_m320(torch),
                                  "wbfm_single": secondary_wbfm(torch),
                                  "nbfm_bank": secondary_nbfm(torch),
                                  "c4fm_bank": secondary_c4fm(torch), "ddc_bank": secondary_ddc(torch),
                                  **_secondary_small_rows(torch)}
+        if "secondary" in line and "pfb_stats_only" in line["secondary"]:
+            line["secondary"]["pfb_stats_only"]["speedup_vs_full_output_pass"] = round(
+                ms_per_step / line["secondary"]["pfb_stats_only"]["ms_per_call"], 3)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

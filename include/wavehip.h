@@ -190,6 +190,15 @@ int wh_pfb_extract_channel(const float *d_out, size_t hops, int channel_count, i
 int wh_pfb_channel_stats(wh_pfb *p, const float *d_out, size_t hops, double *d_stats, int accumulate,
                          void *stream);
 
+/* Statistics-only pass (the scanner's / classifier's real workload: scanner.py:203-208, channel_classifier.py:100-125 need
+ * per-channel power statistics, not samples): the filterbank runs as in wh_pfb_run / wh_pfb_run_i16 (input_format 0 / 1),
+ * carries its history, but the last FFT pass reduces |y|^2 into {sum, sum of squares, min, max} in registers instead of
+ * storing the 16 bytes per input sample of channel outputs; d_stats float64 [M][5] as wh_pfb_channel_stats over ALL hops
+ * of the call (accumulate != 0 merges).  Sums are added in a different order than wh_pfb_channel_stats (agreement 1e-12
+ * relative, not bitwise).  Channel counts with a shaped kernel only (64 ... 2048 of the table; else WH_E_ARG). */
+int wh_pfb_run_stats(wh_pfb *p, const void *d_iq, int input_format, size_t n_samples, double *d_stats, int accumulate,
+                     void *stream);
+
 /* Cross-stream merge of the activity statistics (cc_scanner.py:355-400 / channel_classifier.py:17-48
  * across device streams): d_gathered float64 [n_ranks][n_channels][5] -- the blocks wh_pfb_channel_stats wrote on every
  * GPU, brought together by ONE all-gather (RCCL ncclAllGather on these caller-owned buffers, or torch.distributed) --

@@ -964,6 +964,43 @@ def test_a7_pfb_prefetch_forms_agree(wh):
     assert all(torch.equal(ref, o) for v in outs for o in outs[v])
 
 
+@pytest.mark.parametrize("M", [320, 1024, 256, 96, 2048, 640])
+def test_a13_statistics_only_filterbank(wh, M):
+    """wh_pfb_run_stats: the filterbank in statistics-only mode (last pass reduces |y|^2 in registers, no channel outputs
+    written) == wh_pfb_channel_stats over the full output of the same input: {sum, sum of squares, count, min, max} per
+    channel to 1e-12 relative (sums are added in another order), history carried identically, two calls accumulate, int16
+    input; a channel count without a shaped kernel is refused."""
+    import torch
+
+    fs, bw = M * 25_000, 25_000
+    g = torch.Generator(device="cuda").manual_seed(60 + M)
+    n1, n2 = M // 2 * 700 + 33, M // 2 * 5 + 7
+    x = torch.view_as_complex(torch.randn(n1 + n2, 2, device="cuda", generator=g).mul_(0.5))
+    # (M = 1024: the full output of the SAME kernel family -- the tuned 1024-channel kernel factors its FFT differently, and
+    # float32 rounding differences of y become 1e-7 relative differences of |y|^2)
+    full, st = wh.PolyphaseChannelizer(fs, bw).tune(path="shaped"), wh.PolyphaseChannelizer(fs, bw)
+    assert full.channel_count == M
+    ref = None
+    got = None
+    for lo, hi in ((0, n1), (n1, n1 + n2)):
+        y = full.process_device(x[lo:hi])
+        ref = full.channel_stats_device(y, ref, accumulate=ref is not None)
+        got = st.process_stats_device(x[lo:hi], got, accumulate=got is not None)
+        assert np.array_equal(full.arm_history, st.arm_history)
+    r, s = ref.cpu().numpy(), got.cpu().numpy()
+    assert np.array_equal(r[:, 2], s[:, 2])
+    assert np.max(np.abs(r - s) / np.maximum(np.abs(r), 1e-300)) <= 1e-12, np.max(np.abs(r - s) / np.maximum(np.abs(r), 1e-300))
+    i16 = torch.from_numpy(S.pack_iq16_np(x[:n1].cpu().numpy())).cuda()
+    a, b = wh.PolyphaseChannelizer(fs, bw).tune(path="shaped"), wh.PolyphaseChannelizer(fs, bw)
+    r16 = a.channel_stats_device(a.process_device(i16)).cpu().numpy()
+    s16 = b.process_stats_device(i16).cpu().numpy()
+    assert np.max(np.abs(r16 - s16) / np.maximum(np.abs(r16), 1e-300)) <= 1e-12
+    if M == 320:
+        odd = wh.PolyphaseChannelizer(2_800_000, 100_000)      # M = 28: no shaped kernel
+        with pytest.raises(RuntimeError):
+            odd.process_stats_device(x[:28 * 50])
+
+
 def test_a13_stats_merge_kernel(wh):
     """wh_stats_merge (the device half of the cross-stream activity reduction: gathered [ranks][M][5] -> [M][5]) equals the
     host merge of scanner_reduce bit for bit, for 1, 2 and 8 ranks."""

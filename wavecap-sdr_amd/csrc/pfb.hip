@@ -809,6 +809,8 @@ struct wh_pfb {
     int cur = 0;
     double *d_part = nullptr;   // stats partials
     float2 *d_sink = nullptr;   // [M] write-only scratch row of the shaped kernels
+    double *d_stats_ws = nullptr;   // statistics-only mode: one [4][M] row per workgroup of the launch
+    size_t stats_ws_rows = 0;
     int cu_count = 256;
     int gpw_override = 0;       // wh_pfb_tune(WH_PFB_TUNE_HOPS_PER_RUN)
     int ablate = 0;             // diagnostics build only (WH_PFB_ABLATE)
@@ -875,6 +877,7 @@ extern "C" void wh_pfb_destroy(wh_pfb *p) {
     (void)hipFree(p->d_hist[1]);
     (void)hipFree(p->d_part);
     (void)hipFree(p->d_sink);
+    (void)hipFree(p->d_stats_ws);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
     delete p;
@@ -1014,6 +1017,7 @@ static int pfb_run_fmt(wh_pfb *p, const void *d_iq, int fmt, size_t n, float *d_
         c.sink = p->d_sink;
         c.arms = p->d_arms; c.tw = p->d_tw;
         c.H = H; c.cu_count = p->cu_count; c.hops_per_run = p->gpw_override; c.stats_only = 0;
+        c.stats_ws = nullptr; c.stats_out = nullptr; c.stats_accumulate = 0;
 #ifdef WH_DIAG
         c.stats_only = p->ablate << 8;
 #endif
@@ -1192,6 +1196,44 @@ extern "C" int wh_diag_stream_1r2w(const float *d_in, float *d_out, size_t n, vo
     else if (mode == 2) hipLaunchKernelGGL(stream_1r2w_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), in4, out4, n4);
     else hipLaunchKernelGGL(stream_1r2w_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), in4, out4, n4);
     WH_LAUNCH_CHECK();
+    return WH_OK;
+}
+
+extern "C" int wh_pfb_run_stats(wh_pfb *p, const void *d_iq, int input_format, size_t n, double *d_stats, int accumulate,
+                                void *stream) {
+    if (!p) return set_err(WH_E_ARG, "wh_pfb_run_stats: null handle");
+    if (input_format != 0 && input_format != 1) return set_err(WH_E_ARG, "wh_pfb_run_stats: input_format 0 (complex64) / 1 (int16)");
+    if (!p->mid_ok) return set_err(WH_E_ARG, "wh_pfb_run_stats: no shaped kernel for M=%d T=%d (run + wh_pfb_channel_stats instead)", p->M, p->T);
+    hipStream_t st = as_stream(stream);
+    const long long H = (long long)wh_pfb_hops(p, n);
+    if (H == 0) return WH_OK;
+    if (!d_iq || !d_stats) return set_err(WH_E_ARG, "wh_pfb_run_stats: null buffer");
+    PfbMidCall c;
+    c.x = d_iq; c.fmt = input_format; c.n = n;
+    c.hist = p->d_hist[p->cur]; c.new_hist = p->d_hist[p->cur ^ 1];
+    c.out = nullptr; c.sink = p->d_sink;
+    c.arms = p->d_arms; c.tw = p->d_tw;
+    c.H = H; c.cu_count = p->cu_count; c.hops_per_run = p->gpw_override;
+    c.stats_only = 1; c.stats_ws = nullptr; c.stats_out = d_stats; c.stats_accumulate = accumulate;
+    long long grid = 0;
+    int rc = pfb_mid_launch(p->M, p->T, c, st, &grid);
+    if (rc != WH_OK) return rc;
+    if ((size_t)grid > p->stats_ws_rows) {      // grow the workspace (synchronises; a steady call size never does)
+        WH_HIP(hipStreamSynchronize(st));
+        (void)hipFree(p->d_stats_ws);
+        p->d_stats_ws = nullptr;
+        p->stats_ws_rows = 0;
+        WH_HIP(hipMalloc(&p->d_stats_ws, (size_t)grid * 4 * p->M * sizeof(double)));
+        p->stats_ws_rows = (size_t)grid;
+    }
+    c.stats_ws = p->d_stats_ws;
+    if (p->prof) WH_HIP(hipEventRecord(p->ev0, st));
+    if ((rc = pfb_mid_launch(p->M, p->T, c, st)) != WH_OK) return rc;
+    if (p->prof) {
+        WH_HIP(hipEventRecord(p->ev1, st));
+        p->ev_valid = true;
+    }
+    p->cur ^= 1;
     return WH_OK;
 }
 

@@ -18,13 +18,17 @@ struct PfbMidCall {
     long long H;             // hops of this call (> 0)
     int cu_count;
     int hops_per_run;        // 0 = choose; tuning override otherwise
-    int stats_only;          // 1: do not store the channel outputs (statistics epilogue only; reserved)
+    int stats_only;          // bit 0: statistics-only mode (no channel outputs are stored)
+    double *stats_ws;        // statistics-only: workspace [workgroups][4][M] (sized from the planned grid)
+    double *stats_out;       // statistics-only: float64 [M][5] = {sum p, sum p^2, hops, min p, max p}
+    int stats_accumulate;    // merge into stats_out instead of overwriting
 };
 
 // true when a compiled instance exists for (M, T)
 bool pfb_mid_supported(int M, int T);
-// one launch: head hops (carried history), the runs, and the history update.  Returns a WH_* status.
-int pfb_mid_launch(int M, int T, const PfbMidCall &c, hipStream_t st);
+// one launch: head hops (carried history), the runs, and the history update.  Returns a WH_* status.  With grid_out
+// nothing is launched and the planned grid size is returned (the statistics workspace has one row per workgroup).
+int pfb_mid_launch(int M, int T, const PfbMidCall &c, hipStream_t st, long long *grid_out = nullptr);
 // kernel name fragment for profiles / bench reporting
 const char *pfb_mid_kernel_name();
 

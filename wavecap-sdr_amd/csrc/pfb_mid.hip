@@ -156,6 +156,7 @@ struct MidArgs {
     long long max_block;   // last half-block index fully inside the input
     int hpr;               // hops per run (multiple of GH)
     int n_head;            // workgroups [0, n_head) do the head hops, workgroup n_head the history, the rest the runs
+    double *stats_ws;      // statistics-only mode: [gridDim.x][4][M] per-workgroup {sum p, sum p^2, min p, max p}
 #ifdef WH_DIAG
     int ablate;            // diagnostics build: bit 0 = output stores to the sink, bit 1 = no prefetch loads, bit 2 = no passes
     long long *stamps;     // diagnostics build: [wave][group][4] cycle stamps of workgroup stamp_wg (nullptr = off)
@@ -258,6 +259,20 @@ struct MidCfg {
         return 0;
     }
     static constexpr int LSU = WAVE_MODE ? 0 : pick_lsu();
+    // statistics-only mode (activity scan): the last pass keeps {sum p, sum p^2, min p, max p} of its outputs in registers
+    // instead of storing them.  Units are dealt chunk-major, so that a lane meets few distinct channels: NCD chunks x RL.
+    static constexpr int S_HR = LSU > 0 ? 64 / LSU : 1, S_KC = LSU > 0 ? BPL / LSU : 1, S_NHG = NIMG / S_HR;
+    static constexpr int S_UPW = (S_NHG * S_KC) / NW;
+    static constexpr int NCD = S_UPW % S_NHG == 0 ? S_UPW / S_NHG : 1;
+    static constexpr int NACC = NCD * RL;
+    // the accumulators cost 8 registers per channel: the statistics variant is held to fewer waves per SIMD (as few as
+    // still fit one workgroup on the CU's 4 SIMDs)
+#ifndef WH_WPE_STATS_MIN
+#define WH_WPE_STATS_MIN 2
+#endif
+    static constexpr int WPE_STATS = (NW + 3) / 4 > WH_WPE_STATS_MIN ? (NW + 3) / 4 : WH_WPE_STATS_MIN;
+    static constexpr bool STATS_OK = LSU > 0 && (S_UPW % S_NHG == 0 || S_NHG % S_UPW == 0) && NACC <= 48 &&
+                                     (long long)NIMG * IMGS >= 4LL * M;   // the [M][4] staging fits the image memory
 };
 
 // ---- passes, generic form: butterflies flattened over TH cooperating threads (any shape; index arithmetic per butterfly)
@@ -413,12 +428,47 @@ __device__ __forceinline__ void mid_last_units(const v2f *img, v2f *out, v2f *si
     }
 }
 
+// last pass in statistics-only mode: same butterflies, outputs reduced into the lane's accumulators (p = re^2 + im^2 in
+// float64, as wh_pfb_channel_stats computes it) instead of stored.  Units chunk-major: ui = c S_NHG + hg.
+template <class C>
+__device__ __forceinline__ void mid_last_stats(const v2f *img, int lane, int wave, long long hop0, int stride_r,
+                                               long long limit, double (&acc)[C::NACC][4]) {
+    constexpr int r = C::RL, LSU = C::LSU, HR = C::S_HR, NHG = C::S_NHG, UPW = C::S_UPW;
+    const int hs = HR == 1 ? 0 : lane / LSU, kl = lane - hs * LSU;
+    const v2f *base = img + hs * C::IMGS + C::ph(C::pos_of(kl));
+#pragma unroll
+    for (int i = 0; i < UPW; ++i) {
+        const int ui = wave * UPW + i;               // wave-uniform
+        const int c = ui / NHG, hg = ui - c * NHG;
+        const int ci = UPW % NHG == 0 ? i / NHG : 0; // which of the lane's chunks (compile time)
+        const int s = hg * HR + hs;
+        const long long hop = hop0 + (long long)(s / C::GH) * stride_r + (s % C::GH);
+        const v2f *q = base + hg * HR * C::IMGS + C::ph(C::pos_of(LSU * c));
+        v2f v[r];
+#pragma unroll
+        for (int j = 0; j < r; ++j) v[j] = q[j];
+        bfly(v);
+        if (hop < limit) {
+#pragma unroll
+            for (int k = 0; k < r; ++k) {
+                const double p = (double)v[k].x * (double)v[k].x + (double)v[k].y * (double)v[k].y;
+                double (&a4)[4] = acc[ci * r + k];
+                a4[0] += p;
+                a4[1] += p * p;
+                a4[2] = fmin(a4[2], p);
+                a4[3] = fmax(a4[3], p);
+            }
+        }
+    }
+}
+
 // the passes of the hop images + their stores.  Wave mode: wave w < NWF owns images [w HPW, (w+1) HPW), no workgroup
 // barrier inside.  Workgroup mode: every thread takes part in every pass (barriers between them), then wave w does the
 // last pass of images [w HPL, (w+1) HPL).  Every wave of the workgroup must call this in workgroup mode.
-template <class C>
+template <class C, bool STATS = false>
 __device__ __forceinline__ void mid_transform(v2f *img, const v4f *twp, v2f *out, v2f *sink, int tid, int wave,
-                                              long long hop_g, int stride_r, long long limit) {
+                                              long long hop_g, int stride_r, long long limit,
+                                              double (*acc)[4] = nullptr) {
     // opaque copy of the thread index: the image / twiddle / output offsets of the passes are loop invariant and would
     // otherwise be hoisted out of the group loop and parked in registers for the whole run
     int lt = C::WAVE_MODE ? (tid & 63) : tid;
@@ -431,7 +481,9 @@ __device__ __forceinline__ void mid_transform(v2f *img, const v4f *twp, v2f *out
         }
     } else {
         mid_passes_affine<C, 0, C::TH, C::NIMG, true>(img, twp, lt);
-        if constexpr (C::LSU > 0) mid_last_units<C>(img, out, sink, lt & 63, wave, hop_g, stride_r, limit);
+        if constexpr (STATS) mid_last_stats<C>(img, lt & 63, wave, hop_g, stride_r, limit,
+                                               *reinterpret_cast<double (*)[C::NACC][4]>(acc));
+        else if constexpr (C::LSU > 0) mid_last_units<C>(img, out, sink, lt & 63, wave, hop_g, stride_r, limit);
         else mid_last_generic<C, C::NTL, C::NIMG>(img, out, sink, lt, 0, hop_g, stride_r, limit);
     }
 }
@@ -503,8 +555,44 @@ __device__ __forceinline__ void mid_mac_group(const MidArgs &a, v2f (&wA)[C::T +
     }
 }
 
-template <class C, int FMT>
-__global__ __launch_bounds__(C::NTL) __attribute__((amdgpu_waves_per_eu(C::WPE, C::WPE))) void pfb_mid_kernel(MidArgs a) {
+// the workgroup's accumulators -> [M][4] float64 in LDS (the image memory, free by now) -> its row of the workspace
+template <class C>
+__device__ __forceinline__ void mid_stats_flush(v2f *img, double (&acc)[C::NACC][4], double *ws_row, int tid, int wave) {
+    constexpr int M = C::M, r = C::RL, LSU = C::LSU, NHG = C::S_NHG, UPW = C::S_UPW;
+    double *stg = reinterpret_cast<double *>(img);                       // [4][M]: sum, sum^2, min, max
+    unsigned long long *stgu = reinterpret_cast<unsigned long long *>(img);
+    __syncthreads();
+    for (int i = tid; i < M; i += C::NTL) {
+        stg[i] = 0.0;
+        stg[M + i] = 0.0;
+        stgu[2 * M + i] = 0x7ff0000000000000ULL;   // +inf
+        stgu[3 * M + i] = 0ULL;
+    }
+    __syncthreads();
+    const int lane = tid & 63;
+    const int hs = C::S_HR == 1 ? 0 : lane / LSU, kl = lane - hs * LSU;
+    (void)hs;
+#pragma unroll
+    for (int ci = 0; ci < C::NCD; ++ci) {
+        const int c = (wave * UPW) / NHG + ci;       // the lane's chunk(s), as dealt in mid_last_stats
+#pragma unroll
+        for (int k = 0; k < r; ++k) {
+            const int ch = kl + LSU * c + k * C::BPL;
+            const double (&a4)[4] = acc[ci * r + k];
+            atomicAdd(&stg[ch], a4[0]);
+            atomicAdd(&stg[M + ch], a4[1]);
+            atomicMin(&stgu[2 * M + ch], (unsigned long long)__double_as_longlong(a4[2]));   // p >= 0: bit patterns order like values
+            atomicMax(&stgu[3 * M + ch], (unsigned long long)__double_as_longlong(a4[3]));
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 4 * M; i += C::NTL) ws_row[i] = stg[i];
+}
+
+template <class C, int FMT, bool STATS = false>
+__global__ __launch_bounds__(C::NTL) __attribute__((amdgpu_waves_per_eu(STATS ? C::WPE_STATS : C::WPE,
+                                                                          STATS ? C::WPE_STATS : C::WPE)))
+void pfb_mid_kernel(MidArgs a) {
     constexpr int M = C::M, T = C::T, R = C::R, GH = C::GH, Q = C::Q, HB = C::HB, NT = C::NTL, NIMG = C::NIMG;
     constexpr int IMGS = C::IMGS, TREG = C::TREG, NL4 = C::NL4;
     constexpr MidPlan P = C::P;
@@ -518,6 +606,11 @@ __global__ __launch_bounds__(C::NTL) __attribute__((amdgpu_waves_per_eu(C::WPE, 
 
     const int tid = threadIdx.x;
     const int bid = blockIdx.x;
+    double acc[STATS ? C::NACC : 1][4];
+    if (STATS) {
+#pragma unroll
+        for (int i = 0; i < C::NACC; ++i) { acc[i][0] = 0.0; acc[i][1] = 0.0; acc[i][2] = __longlong_as_double(0x7ff0000000000000LL); acc[i][3] = 0.0; }
+    }
 
     if (bid == a.n_head) {   // history for the next call: new_hist[k][j] = block_{H-1-j}[k]
         for (int idx = tid; idx < M * T; idx += NT) {
@@ -587,7 +680,9 @@ __global__ __launch_bounds__(C::NTL) __attribute__((amdgpu_waves_per_eu(C::WPE, 
             L[C::ph(3 * Q)] = cmul3(z[3], v2f{w3.x, w3.y});
         }
         __syncthreads();   // images and twiddle tables
-        mid_transform<C>(img, twp, a.out, a.sink, tid, wave, hop_base, GH, limit);
+        mid_transform<C, STATS>(img, twp, a.out, a.sink, tid, wave, hop_base, GH, limit, acc);
+        if constexpr (STATS) mid_stats_flush<C>(img, *reinterpret_cast<double (*)[C::NACC][4]>(acc),
+                                                a.stats_ws + (size_t)bid * 4 * M, tid, wave);
         return;
     }
 
@@ -649,10 +744,39 @@ __global__ __launch_bounds__(C::NTL) __attribute__((amdgpu_waves_per_eu(C::WPE, 
         if (C::SELF) __builtin_amdgcn_wave_barrier();
         else __syncthreads();
         WH_STAMP(2)
-        if (passes) mid_transform<C>(img, twp, a.out, a.sink, tid, wave, hop_g, a.hpr, limit);
+        if (passes) mid_transform<C, STATS>(img, twp, a.out, a.sink, tid, wave, hop_g, a.hpr, limit, acc);
         WH_STAMP(3)
         if (C::SELF) __builtin_amdgcn_wave_barrier();
         else __syncthreads();
+    }
+    if constexpr (STATS) mid_stats_flush<C>(img, *reinterpret_cast<double (*)[C::NACC][4]>(acc),
+                                            a.stats_ws + (size_t)bid * 4 * M, tid, wave);
+}
+
+// statistics-only mode, second step: the workgroups' rows [rows][4][M] -> d_stats [M][5] = {sum p, sum p^2, hops, min, max}
+// (row `skip` belongs to the history workgroup and holds nothing).  One block of (64 channels) x (16 row slices).
+__global__ __launch_bounds__(1024) void mid_stats_reduce_kernel(const double *ws, int rows, int skip, int M, double hops,
+                                                               double *stats, int accumulate) {
+    const int c = blockIdx.x * 64 + threadIdx.x, y = threadIdx.y;
+    double s = 0, s2 = 0, mn = 1e300, mx = 0;
+    if (c < M)
+        for (int r = y; r < rows; r += 16) {
+            if (r == skip) continue;
+            const double *p = ws + (size_t)r * 4 * M + c;
+            s += p[0]; s2 += p[M];
+            mn = fmin(mn, p[2 * M]); mx = fmax(mx, p[3 * M]);
+        }
+    __shared__ double red[4][16][64];
+    red[0][y][threadIdx.x] = s; red[1][y][threadIdx.x] = s2; red[2][y][threadIdx.x] = mn; red[3][y][threadIdx.x] = mx;
+    __syncthreads();
+    if (y == 0 && c < M) {
+        for (int k = 1; k < 16; ++k) {
+            s += red[0][k][threadIdx.x]; s2 += red[1][k][threadIdx.x];
+            mn = fmin(mn, red[2][k][threadIdx.x]); mx = fmax(mx, red[3][k][threadIdx.x]);
+        }
+        double *o = stats + (size_t)c * 5;
+        if (accumulate) { o[0] += s; o[1] += s2; o[2] += hops; o[3] = fmin(o[3], mn); o[4] = fmax(o[4], mx); }
+        else { o[0] = s; o[1] = s2; o[2] = hops; o[3] = mn; o[4] = mx; }
     }
 }
 
@@ -712,10 +836,11 @@ int g_diag_stamp_wg = 0;
     X(4096, 1, 2, 0, 2, 1024, 1, 0, 36, 0)
 
 template <class C>
-int mid_launch_t(const PfbMidCall &c, hipStream_t st) {
+int mid_launch_t(const PfbMidCall &c, hipStream_t st, long long *grid_out) {
     constexpr int M = C::M, T = C::T, R = C::R, GH = C::GH, NT = C::NTL, NIMG = C::NIMG;
     static int wg_per_cu[2] = {0, 0};   // resident workgroups per CU of the two format instances
     const int f = c.fmt == 1 ? 1 : 0;
+    if (c.stats_only && !C::STATS_OK) return set_err(WH_E_ARG, "wh_pfb_run_stats: no statistics-only form for M=%d", C::M);
     auto kern = f ? pfb_mid_kernel<C, 1> : pfb_mid_kernel<C, 0>;
     if (wg_per_cu[f] == 0) {
         // by registers: the kernel is compiled for WPE waves per SIMD (4 SIMDs per CU); by LDS: 160 KiB per CU
@@ -753,7 +878,7 @@ int mid_launch_t(const PfbMidCall &c, hipStream_t st) {
     }
     a.hpr = hpr;
 #ifdef WH_DIAG
-    a.ablate = c.stats_only >> 8;   // diagnostics build: wh_pfb_tune(key 4) rides in the upper bits
+    a.ablate = c.stats_only >> 8;   // diagnostics build: wh_pfb_tune(key 4) rides in the upper bits of stats_only
     a.stamps = g_diag_stamps;
     a.stamp_wg = g_diag_stamp_wg;
 #endif
@@ -761,6 +886,23 @@ int mid_launch_t(const PfbMidCall &c, hipStream_t st) {
     a.n_head = (int)((head_hops + NIMG - 1) / NIMG);
     const long long grid = a.n_head + 1 + n_main;
     if (grid > 0x7fffffffLL) return set_err(WH_E_ARG, "wh_pfb_run: input too long for one launch");
+    if (grid_out) {           // plan only: the caller sizes the statistics workspace from it
+        *grid_out = grid;
+        return WH_OK;
+    }
+    a.stats_ws = c.stats_ws;
+    if (c.stats_only & 1) {
+        if constexpr (C::STATS_OK) {
+            if (!c.stats_ws || !c.stats_out) return set_err(WH_E_ARG, "wh_pfb_run_stats: null statistics buffer");
+            auto skern = f ? pfb_mid_kernel<C, 1, true> : pfb_mid_kernel<C, 0, true>;
+            hipLaunchKernelGGL(skern, dim3((unsigned)grid), dim3(NT), 0, st, a);
+            WH_LAUNCH_CHECK();
+            hipLaunchKernelGGL(mid_stats_reduce_kernel, dim3((M + 63) / 64), dim3(64, 16), 0, st, c.stats_ws, (int)grid,
+                               a.n_head, M, (double)c.H, c.stats_out, c.stats_accumulate);
+            WH_LAUNCH_CHECK();
+            return WH_OK;
+        }
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), 0, st, a);
     WH_LAUNCH_CHECK();
     return WH_OK;
@@ -782,10 +924,10 @@ bool pfb_mid_supported(int M, int T) {
     return false;
 }
 
-int pfb_mid_launch(int M, int T, const PfbMidCall &c, hipStream_t st) {
+int pfb_mid_launch(int M, int T, const PfbMidCall &c, hipStream_t st, long long *grid_out) {
     if (T == 9) {
 #define X(M_, R_, GH_, NWF_, WPE_, PB_, PADN_, IMGX_, TREG_, LSP_) \
-    if (M == M_) return mid_launch_t<MidCfg<M_, 9, R_, GH_, NWF_, WPE_, PB_, PADN_, IMGX_, TREG_, LSP_>>(c, st);
+    if (M == M_) return mid_launch_t<MidCfg<M_, 9, R_, GH_, NWF_, WPE_, PB_, PADN_, IMGX_, TREG_, LSP_>>(c, st, grid_out);
         WH_MID_CONFIGS(X)
 #undef X
     }

@@ -108,6 +108,7 @@ PROTOTYPES = {
     "wh_pfb_reset": (c_int, [c_void_p, c_void_p]),
     "wh_pfb_get_history": (c_int, [c_void_p, c_void_p, c_void_p]),
     "wh_pfb_set_history": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "wh_pfb_run_stats": (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_void_p, c_int, c_void_p]),
     "wh_stats_merge": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "wh_pfb_tune": (c_int, [c_void_p, c_int, c_int]),
     "wh_pfb_profile": (c_int, [c_void_p, c_int]),

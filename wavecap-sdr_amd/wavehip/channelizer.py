@@ -140,6 +140,21 @@ class PolyphaseChannelizer:
                    "wh_pfb_channel_stats")
         return stats
 
+    def process_stats_device(self, samples, stats=None, accumulate: bool = False):
+        """Statistics-only pass (wh_pfb_run_stats): the per-channel activity statistics [M, 5] float64 of ALL hops of
+        `samples` (GPU tensor, complex64 or interleaved int16) without writing the channel outputs; history carried like
+        process_device()."""
+        torch = self._torch
+        assert samples.is_cuda and samples.is_contiguous()
+        fmt = 1 if samples.dtype == torch.int16 else 0
+        n = samples.numel() // (2 if fmt else 1)
+        if stats is None:
+            stats = torch.zeros((self.channel_count, 5), dtype=torch.float64, device=samples.device)
+            accumulate = False
+        _lib.check(_lib.lib.wh_pfb_run_stats(self._h, samples.data_ptr(), fmt, n, stats.data_ptr(), 1 if accumulate else 0,
+                                             _lib.stream_ptr(torch)), "wh_pfb_run_stats")
+        return stats
+
     def extract_channel(self, channel_results, channel_index: int):
         """channelizer.py:144-158."""
         torch = self._torch
