@@ -126,17 +126,17 @@ def evaluate(M, R, GH, PB, PADN, IMGX, LSP=0, T=9):
                 plan=rad, LSL=LSL, LSP=LSP, putil=putil)
 
 
-def best(M):
+def best(M, force_R=None):
     Q = M // 4
     pl = plan(Q)
     if not pl: return None
     rad, Ls = pl
     cands = []
     pbs = sorted({0, Q} | set(Ls[1:]))
-    for R in range(1, 17):
+    for R in ([force_R] if force_R else range(1, 17)):
         NT = R * Q
         NW = (NT + 63) // 64
-        if NW > 16 or NT / (NW * 64) < 0.88: continue
+        if NW > 16 or (not force_R and NT / (NW * 64) < 0.88): continue
         for GH in (4, 3, 2, 5, 6, 8):
             for PB in pbs:
                 for PADN in ((0,) if PB == 0 else (1, 2)):
@@ -154,9 +154,10 @@ def best(M):
 
 
 if __name__ == "__main__":
-    for M in (int(a) for a in sys.argv[1:]):
-        b = best(M)
+    for arg in sys.argv[1:]:
+        M, fr = (int(v) for v in arg.split(":")) if ":" in arg else (int(arg), None)
+        b = best(M, fr)
         if not b: print(f"M={M}: no workgroup-mode shape"); continue
-        wpe = 3 if b["NW"] in (4, 12) else 2
+        wpe = 3 if b["NW"] in (3, 4, 12) else 2
         print(f"    X({M}, {b['R']}, {b['GH']}, 0, {wpe}, {b['PB']}, {b['PADN']}, {b['IMGX']}, 36, {b['LSP']}) \\   // plan {b['plan']} waves {b['NW']} lanes/hop {b['LS']} "
               f"util {b['util']:.2f} pass-util {b['putil']:.2f} last-pass lanes/hop {b['LSL']} LDS {b['lds']} B conflicts rd x{b['rd']:.2f} wr x{b['wr']:.2f}")

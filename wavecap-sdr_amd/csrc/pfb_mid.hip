@@ -828,7 +828,7 @@ int g_diag_stamp_wg = 0;
     X(480, 2, 4, 0, 3, 5, 2, 4, 36, 20) \
     X(512, 2, 4, 0, 3, 32, 2, 0, 36, 0) \
     X(640, 3, 4, 0, 2, 40, 2, 3, 36, 0) \
-    X(768, 4, 3, 0, 3, 48, 2, 0, 36, 0) \
+    X(768, 1, 3, 0, 3, 48, 2, 0, 36, 0) \
     X(800, 3, 4, 0, 2, 200, 2, 0, 36, 40) \
     X(960, 1, 4, 0, 3, 5, 2, 4, 36, 40) \
     X(1280, 1, 5, 0, 2, 80, 2, 0, 36, 0) \
