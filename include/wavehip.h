@@ -350,6 +350,28 @@ void wh_lsm_bank_destroy(wh_lsm_bank *b);
 
 /* Gardner timing error detector bank, dsp/p25/symbol_timing.py:60-211 (GardnerTED.process_block):
  * d_x float32 [C][stride] -> d_symbols / d_errors float64 [C][cap], d_counts int32 [C].       */
+/* CostasLoop, dsp/p25/cqpsk.py:84-196, as a bank (standalone drop-in; the same loop runs fused inside wh_cqpsk_bank_run):
+ * per sample corrected = x exp(-j phase); decision-directed pi/4 phase detector; PI loop filter with the frequency clipped
+ * to +-max_freq; phase wrapped.  d_x, d_out: complex128 [n_channels][stride] (n used); h_freq (optional, synchronous):
+ * the loop's frequency estimates after the call (the frequency_offset property).  kp / ki from loop_bw and damping as
+ * cqpsk.py:107-110 computes them. */
+typedef struct wh_costas_bank wh_costas_bank;
+int wh_costas_bank_create(wh_costas_bank **out, int n_channels, double kp, double ki, double max_freq);
+int wh_costas_bank_run(wh_costas_bank *b, const double *d_x, size_t n, size_t stride, double *d_out, double *h_freq,
+                       void *stream);
+int wh_costas_bank_reset(wh_costas_bank *b, void *stream);
+void wh_costas_bank_destroy(wh_costas_bank *b);
+
+/* MuellerMullerTED, dsp/p25/symbol_timing.py:214-380, as a bank: complex128 samples in; per symbol the cubic-interpolated
+ * sample, the nearest point of (+-1 +-j)/sqrt 2 and the timing error Re{conj(d[n-1]) x[n] - conj(d[n]) x[n-1]};
+ * d_symbols / d_decisions complex128 [n_channels][cap], d_errors float64 [n_channels][cap], d_counts int32. */
+typedef struct wh_mm_bank wh_mm_bank;
+int wh_mm_bank_create(wh_mm_bank **out, int n_channels, double samples_per_symbol, double kp, double ki);
+int wh_mm_bank_run(wh_mm_bank *b, const double *d_x, size_t n, size_t stride, double *d_symbols, double *d_decisions,
+                   double *d_errors, size_t cap, int32_t *d_counts, void *stream);
+int wh_mm_bank_reset(wh_mm_bank *b, void *stream);
+void wh_mm_bank_destroy(wh_mm_bank *b);
+
 typedef struct wh_gardner_bank wh_gardner_bank;
 int wh_gardner_bank_create(wh_gardner_bank **out, int n_channels, double samples_per_symbol, double kp, double ki);
 int wh_gardner_bank_run(wh_gardner_bank *g, const float *d_x, size_t n, size_t stride, double *d_symbols,

@@ -102,6 +102,11 @@ pairs = [
     ("ChannelClassifier.update", rcc.ChannelClassifier.update, wavehip.ChannelClassifier.update),
     ("P25P1SoftSyncDetector.process_batch", rfr.P25P1SoftSyncDetector.process_batch, wavehip.P25P1SoftSyncDetector.process_batch),
     ("GardnerTED.__init__", rst.GardnerTED.__init__, wavehip.GardnerTED.__init__),
+    ("MuellerMullerTED.__init__", rst.MuellerMullerTED.__init__, wavehip.MuellerMullerTED.__init__),
+    ("MuellerMullerTED.process_block", rst.MuellerMullerTED.process_block, wavehip.MuellerMullerTED.process_block),
+    ("CostasLoop.__init__", rcq.CostasLoop.__init__, wavehip.CostasLoop.__init__),
+    ("CostasLoop.process", rcq.CostasLoop.process, wavehip.CostasLoop.process),
+    ("CostasLoop.process_block", rcq.CostasLoop.process_block, wavehip.CostasLoop.process_block),
 ]
 for name, a, b in pairs:
     pa, pb = params(a), params(b)

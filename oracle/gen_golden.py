@@ -684,6 +684,25 @@ def gen_cqpsk():
     save("cqpsk", **out)
 
 
+def gen_cqpsk_parts():
+    """A12 parts as standalone drop-ins: CostasLoop (dsp/p25/cqpsk.py:84-196) and MuellerMullerTED
+    (dsp/p25/symbol_timing.py:214-380) on a pi/4-DQPSK carrier, two calls each (carried state)."""
+    from wavecapsdr.dsp.p25.cqpsk import CostasLoop
+    from wavecapsdr.dsp.p25.symbol_timing import MuellerMullerTED
+
+    fs, sr, n, seed = 48000, 12000, 6000, 1700
+    iq, _ = S.dqpsk_iq(n, fs, seed, symbol_rate=sr, snr_db=22.0, freq_offset_hz=60.0)
+    x = iq.astype(np.complex128)
+    cl = CostasLoop()
+    c1, c2 = cl.process_block(x[:3500]), cl.process_block(x[3500:])
+    mm = MuellerMullerTED(fs / sr)
+    a, b = mm.process_block(np.concatenate([c1, c2])[:2500]), mm.process_block(np.concatenate([c1, c2])[2500:])
+    save("cqpsk_parts", args=np.array([fs, sr, n, seed], dtype=np.int64), sha=np.array(S.sha256(iq)),
+         costas=np.concatenate([c1, c2]), costas_freq=np.array([cl.frequency_offset]),
+         mm_counts=np.array([len(a[0]), len(b[0])], dtype=np.int64),
+         mm_sym=np.concatenate([a[0], b[0]]), mm_dec=np.concatenate([a[1], b[1]]), mm_err=np.concatenate([a[2], b[2]]))
+
+
 def gen_framer():
     """N2: P25P1SoftSyncDetector.process_batch (decoders/p25_framer.py:192-231); N4: pack_f32 (capture.py:134-144)."""
     from wavecapsdr.decoders.p25_framer import P25P1SoftSyncDetector
@@ -771,7 +790,7 @@ def gen_lsm():
     save("lsm", **out)
 
 
-ALL = dict(chain4=gen_chain4, blanker=gen_blanker, nid=gen_nid, classifier=gen_classifier, recorder=gen_recorder, nr=gen_nr, sam=gen_sam, rawdig=gen_rawdig, lsm=gen_lsm, framer=gen_framer, cqpsk=gen_cqpsk, trunk=gen_trunk, a1=gen_a1, a2=gen_a2, a3=gen_a3, a6=gen_a6, chain=gen_chain, a7=gen_a7, a8=gen_a8, c4fm=gen_c4fm)
+ALL = dict(cqpsk_parts=gen_cqpsk_parts, chain4=gen_chain4, blanker=gen_blanker, nid=gen_nid, classifier=gen_classifier, recorder=gen_recorder, nr=gen_nr, sam=gen_sam, rawdig=gen_rawdig, lsm=gen_lsm, framer=gen_framer, cqpsk=gen_cqpsk, trunk=gen_trunk, a1=gen_a1, a2=gen_a2, a3=gen_a3, a6=gen_a6, chain=gen_chain, a7=gen_a7, a8=gen_a8, c4fm=gen_c4fm)
 
 if __name__ == "__main__":
     import logging

@@ -970,3 +970,69 @@ def noise_blanker(x: np.ndarray, threshold_db: float = 10.0, blanking_width: int
     y = x.copy()
     y[mask] = 0
     return y.astype(np.float32)
+
+
+# --------------------------------------------------------------------------
+# A12 parts: CostasLoop (dsp/p25/cqpsk.py:84-196) and MuellerMullerTED (dsp/p25/symbol_timing.py:214-380)
+# Pure-Python per-sample loops like the reference (small cases only).
+# --------------------------------------------------------------------------
+
+
+class CostasLoop:
+    def __init__(self, loop_bw: float = 0.01, damping: float = 0.707, max_freq: float = 0.1):
+        theta = loop_bw / (damping + 1 / (4 * damping))          # cqpsk.py:107-110
+        d = 1 + 2 * damping * theta + theta ** 2
+        self._kp, self._ki, self._max_freq = 4 * damping * theta / d, 4 * theta ** 2 / d, max_freq
+        self._phase = self._freq = 0.0
+
+    def process_block(self, samples):
+        out = np.zeros(len(samples), dtype=np.complex128)
+        q = np.pi / 4
+        for i, x in enumerate(np.asarray(samples, dtype=np.complex128)):
+            c = x * np.exp(-1j * self._phase)                        # cqpsk.py:138
+            ph = np.angle(c)                                         # :166-170
+            err = ph - np.round(ph / q) * q
+            while err > np.pi: err -= 2 * np.pi
+            while err < -np.pi: err += 2 * np.pi
+            self._freq = float(np.clip(self._freq + self._ki * err, -self._max_freq, self._max_freq))   # :145-146
+            self._phase += self._kp * err + self._freq
+            while self._phase > np.pi: self._phase -= 2 * np.pi
+            while self._phase < -np.pi: self._phase += 2 * np.pi
+            out[i] = c
+        return out
+
+
+class MuellerMullerTED:
+    CONST = np.array([1 + 1j, -1 + 1j, -1 - 1j, 1 - 1j], dtype=np.complex128) / np.sqrt(2)
+
+    def __init__(self, samples_per_symbol: float, loop_bw: float = 0.01, damping: float = 1.0):
+        theta = loop_bw / (damping + 1 / (4 * damping))          # symbol_timing.py:34-57
+        d = 1 + 2 * damping * theta + theta ** 2
+        self.sps, self._kp, self._ki = samples_per_symbol, 4 * damping * theta / d, 4 * theta ** 2 / d
+        self._phase = self._integ = 0.0
+        self._buf = [0j, 0j, 0j, 0j]                              # oldest ... newest
+        self._prev_sym = self._prev_dec = 0j
+
+    @staticmethod
+    def _interp(v, mu):                                           # symbol_timing.py:296-303
+        c0 = v[1]; c1 = (v[2] - v[0]) / 2
+        c2 = v[0] - 5 * v[1] / 2 + 2 * v[2] - v[3] / 2
+        c3 = (v[3] - v[0]) / 2 + 3 * (v[1] - v[2]) / 2
+        return float(c0 + mu * (c1 + mu * (c2 + mu * c3)))
+
+    def process_block(self, samples):
+        sym, dec, errs = [], [], []
+        for x in np.asarray(samples, dtype=np.complex128):
+            self._buf = self._buf[1:] + [complex(x)]
+            self._phase += 1.0
+            if self._phase >= self.sps:                           # :342-372
+                self._phase -= self.sps
+                mu = self._phase / self.sps
+                cur = complex(self._interp([b.real for b in self._buf], mu), self._interp([b.imag for b in self._buf], mu))
+                d = complex(self.CONST[np.argmin(np.abs(self.CONST - cur))])
+                e = float(np.real(np.conj(self._prev_dec) * cur - np.conj(d) * self._prev_sym))
+                self._integ = float(np.clip(self._integ + self._ki * e, -self.sps / 4, self.sps / 4))
+                self._phase += self._kp * e + self._integ
+                sym.append(cur); dec.append(d); errs.append(e)
+                self._prev_sym, self._prev_dec = cur, d
+        return np.array(sym, np.complex128), np.array(dec, np.complex128), np.array(errs, np.float64)

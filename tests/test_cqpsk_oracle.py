@@ -51,3 +51,24 @@ def test_gardner_oracle_matches_reference(golden):
     t.reset()
     s4, _ = t.process_block(x[:3000])
     assert np.array_equal(s4, s1)
+
+
+def test_costas_and_mueller_muller_oracle_match_reference(golden):
+    """The numpy restatements of CostasLoop (cqpsk.py:84-196) and MuellerMullerTED (symbol_timing.py:214-380) reproduce
+    the reference's outputs on the `cqpsk_parts` golden (two calls each, carried state)."""
+    from oracle import ref_np as O
+
+    g = golden("cqpsk_parts")
+    fs, sr, n, seed = (int(v) for v in g["args"])
+    iq, _ = S.dqpsk_iq(n, fs, seed, symbol_rate=sr, snr_db=22.0, freq_offset_hz=60.0)
+    assert S.sha256(iq) == str(g["sha"])
+    x = iq.astype(np.complex128)
+    cl = O.CostasLoop()
+    c = np.concatenate([cl.process_block(x[:3500]), cl.process_block(x[3500:])])
+    assert np.max(np.abs(c - g["costas"])) <= 1e-12 and abs(cl._freq - float(g["costas_freq"][0])) <= 1e-14
+    mm = O.MuellerMullerTED(fs / sr)
+    a, b = mm.process_block(g["costas"][:2500]), mm.process_block(g["costas"][2500:])
+    assert [len(a[0]), len(b[0])] == [int(v) for v in g["mm_counts"]]
+    assert np.max(np.abs(np.concatenate([a[0], b[0]]) - g["mm_sym"])) <= 1e-12
+    assert np.array_equal(np.concatenate([a[1], b[1]]), g["mm_dec"])
+    assert np.max(np.abs(np.concatenate([a[2], b[2]]) - g["mm_err"])) <= 1e-12

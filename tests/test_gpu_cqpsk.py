@@ -63,3 +63,39 @@ def test_gardner_bit_exact(golden):
     k = int(cnt[0])
     ref = wavehip.GardnerTED(10.0).process_block(x)
     assert np.array_equal(sym[0, :k].cpu().numpy(), ref[0])
+
+
+def test_costas_loop_and_mueller_muller_ted_standalone(golden):
+    """The two loops of the Phase-2 chain as the reference's standalone classes (CostasLoop cqpsk.py:84-196,
+    MuellerMullerTED symbol_timing.py:214-380): outputs within 1e-9 of the reference golden over two calls each (carried
+    state), decisions equal, `process()` one sample at a time == `process_block`, banks == single channels."""
+    import torch
+    import wavehip
+
+    g = golden("cqpsk_parts")
+    fs, sr, n, seed = (int(v) for v in g["args"])
+    iq, _ = S.dqpsk_iq(n, fs, seed, symbol_rate=sr, snr_db=22.0, freq_offset_hz=60.0)
+    x = iq.astype(np.complex128)
+    cl = wavehip.CostasLoop()
+    c = np.concatenate([cl.process_block(x[:3500]), cl.process_block(x[3500:])])
+    assert c.dtype == np.complex128 and np.max(np.abs(c - g["costas"])) <= 1e-9
+    assert abs(cl.frequency_offset - float(g["costas_freq"][0])) <= 1e-9
+    one = wavehip.CostasLoop()
+    assert np.max(np.abs(np.array([one.process(v) for v in x[:40]]) - g["costas"][:40])) <= 1e-9
+    mm = wavehip.MuellerMullerTED(fs / sr)
+    a, b = mm.process_block(g["costas"][:2500]), mm.process_block(g["costas"][2500:])
+    assert [len(a[0]), len(b[0])] == [int(v) for v in g["mm_counts"]]
+    assert np.max(np.abs(np.concatenate([a[0], b[0]]) - g["mm_sym"])) <= 1e-9
+    assert np.max(np.abs(np.concatenate([a[1], b[1]]) - g["mm_dec"])) <= 1e-15
+    assert np.max(np.abs(np.concatenate([a[2], b[2]]) - g["mm_err"])) <= 1e-9
+    # banks: channel k = the stream rotated by k * 10 degrees (the loops see different phases)
+    rot = np.exp(1j * np.deg2rad(10.0) * np.arange(4))[:, None]
+    xb = torch.from_numpy(np.ascontiguousarray(rot * x[None, :])).cuda()
+    cb = wavehip.CostasBank(4).process_device(xb)
+    for k in (0, 3):
+        ref = wavehip.CostasLoop().process_block((rot[k] * x))
+        assert np.max(np.abs(cb[k].cpu().numpy() - ref)) <= 1e-12
+    sb, db, eb, nb = wavehip.MuellerMullerBank(4, fs / sr).process_device(cb)
+    s0 = wavehip.MuellerMullerTED(fs / sr).process_block(cb[0].cpu().numpy())
+    assert int(nb[0]) == len(s0[0]) and np.max(np.abs(sb[0, :len(s0[0])].cpu().numpy() - s0[0])) <= 1e-12
+    assert wavehip.CostasLoop().process_block(np.zeros(0)).size == 0 and len(wavehip.MuellerMullerTED(4.0).process_block([])[0]) == 0

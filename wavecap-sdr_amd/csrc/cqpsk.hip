@@ -247,6 +247,105 @@ __global__ __launch_bounds__(64) void k_cq_seq(CqArgs a) {
     }
 }
 
+// ---- standalone drop-ins of the two loops of the chain (dsp/p25/cqpsk.py:84-196 CostasLoop, symbol_timing.py:214-380
+// MuellerMullerTED): the same per-sample recurrences as k_cq_seq, one wave per channel, complex128 in and out.
+struct CostasState { double phase, freq; };
+
+__global__ __launch_bounds__(64) void k_costas(const double2 *x, size_t stride, int n, CostasState *st, double kp,
+                                               double ki, double maxf, double2 *out, size_t out_stride) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    double phase = st[c].phase, freq = st[c].freq;
+    const double2 *xc = x + (size_t)c * stride;
+    double2 *oc = out + (size_t)c * out_stride;
+    const double q = PI_D / 4, inv_q = 1.0 / (PI_D / 4);
+    for (int t0 = 0; t0 < n; t0 += 64) {
+        const double2 xl = t0 + lane < n ? xc[t0 + lane] : make_double2(0.0, 0.0);
+        const int m = n - t0 < 64 ? n - t0 : 64;
+        double2 mine = make_double2(0.0, 0.0);
+        for (int j = 0; j < m; ++j) {
+            const int xlo = __builtin_amdgcn_readlane(__double2loint(xl.x), j), xhi = __builtin_amdgcn_readlane(__double2hiint(xl.x), j);
+            const int ylo = __builtin_amdgcn_readlane(__double2loint(xl.y), j), yhi = __builtin_amdgcn_readlane(__double2hiint(xl.y), j);
+            const double xr = __hiloint2double(xhi, xlo), xi = __hiloint2double(yhi, ylo);
+            double sn, cs;
+            cq_sincos(phase, sn, cs);
+            const double cr = DS(DM(xr, cs), DM(xi, -sn));     // sample * exp(-j phase)
+            const double ci = DA(DM(xr, -sn), DM(xi, cs));
+            const double ph = cq_atan2(ci, cr);
+            double err = DS(ph, DM(rint(DM(ph, inv_q)), q));
+            err = err > PI_D ? DS(err, 2 * PI_D) : err;
+            err = err < -PI_D ? DA(err, 2 * PI_D) : err;
+            freq = fmin(fmax(DA(freq, DM(ki, err)), -maxf), maxf);
+            phase = DA(phase, DA(DM(kp, err), freq));
+            while (phase > PI_D) phase = DS(phase, 2 * PI_D);
+            while (phase < -PI_D) phase = DA(phase, 2 * PI_D);
+            if (lane == j) mine = make_double2(cr, ci);        // lane j keeps output j: one coalesced store per 64
+        }
+        if (t0 + lane < n) oc[t0 + lane] = mine;
+    }
+    if (lane == 0) { st[c].phase = phase; st[c].freq = freq; }
+}
+
+struct MmState {
+    double phase, integ;
+    double2 b0, b1, b2, b3;      // b3 = newest
+    double2 prev_sym, prev_dec;
+};
+
+__global__ __launch_bounds__(64) void k_mm(const double2 *x, size_t stride, int n, MmState *st, double sps, double kp,
+                                           double ki, double2 *symbols, double2 *decisions, double *errors, size_t cap,
+                                           int *counts) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    MmState *sp = st + c;
+    double phase = sp->phase, integ = sp->integ;
+    double2 b0 = sp->b0, b1 = sp->b1, b2 = sp->b2, b3 = sp->b3, prev_sym = sp->prev_sym, prev_dec = sp->prev_dec;
+    const double2 *xc = x + (size_t)c * stride;
+    const double inv_sps = 1.0 / sps, maxdev = sps / 4, R2 = 0.70710678118654746;
+    int count = 0;
+    for (int t0 = 0; t0 < n; t0 += 64) {
+        const double2 xl = t0 + lane < n ? xc[t0 + lane] : make_double2(0.0, 0.0);
+        const int m = n - t0 < 64 ? n - t0 : 64;
+        for (int j = 0; j < m; ++j) {
+            const int xlo = __builtin_amdgcn_readlane(__double2loint(xl.x), j), xhi = __builtin_amdgcn_readlane(__double2hiint(xl.x), j);
+            const int ylo = __builtin_amdgcn_readlane(__double2loint(xl.y), j), yhi = __builtin_amdgcn_readlane(__double2hiint(xl.y), j);
+            b0 = b1; b1 = b2; b2 = b3; b3 = make_double2(__hiloint2double(xhi, xlo), __hiloint2double(yhi, ylo));
+            phase = DA(phase, 1.0);
+            if (phase >= sps) {
+                phase = DS(phase, sps);
+                const double mu = DM(phase, inv_sps);
+                const double sr = interp1(b0.x, b1.x, b2.x, b3.x, mu), si = interp1(b0.y, b1.y, b2.y, b3.y, mu);
+                int best = 0;
+                double bd = 0.0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const double kr = (k == 0 || k == 3) ? R2 : -R2, kq = (k < 2) ? R2 : -R2;
+                    const double dx = DS(kr, sr), dy = DS(kq, si);
+                    const double d = fma(dx, dx, dy * dy);
+                    if (k == 0 || d < bd) { bd = d; best = k; }
+                }
+                const double dr = (best == 0 || best == 3) ? R2 : -R2, di = best < 2 ? R2 : -R2;
+                const double e = DS(DS(DM(prev_dec.x, sr), DM(-prev_dec.y, si)), DS(DM(dr, prev_sym.x), DM(-di, prev_sym.y)));
+                integ = fmin(fmax(DA(integ, DM(ki, e)), -maxdev), maxdev);
+                phase = DA(phase, DA(DM(kp, e), integ));
+                if ((size_t)count < cap) {
+                    if (lane == 0) {
+                        symbols[(size_t)c * cap + count] = make_double2(sr, si);
+                        decisions[(size_t)c * cap + count] = make_double2(dr, di);
+                        errors[(size_t)c * cap + count] = e;
+                    }
+                    count++;
+                }
+                prev_sym = make_double2(sr, si);
+                prev_dec = make_double2(dr, di);
+            }
+        }
+    }
+    if (lane == 0) {
+        sp->phase = phase; sp->integ = integ;
+        sp->b0 = b0; sp->b1 = b1; sp->b2 = b2; sp->b3 = b3; sp->prev_sym = prev_sym; sp->prev_dec = prev_dec;
+        counts[c] = count;
+    }
+}
+
 struct GState {
     double phase, integ, prev_symbol, prev_mid, b0, b1, b2, b3;
 };
@@ -421,6 +520,102 @@ extern "C" int wh_gardner_bank_run(wh_gardner_bank *g, const float *d_x, size_t 
         return set_err(WH_E_ARG, "wh_gardner_bank_run: bad buffers");
     hipLaunchKernelGGL(k_gardner, dim3((g->C + 63) / 64), dim3(64), 0, st, d_x, stride, (int)n, g->C, g->d_st, g->sps,
                        g->kp, g->ki, d_symbols, d_errors, cap, d_counts);
+    WH_LAUNCH_CHECK();
+    return WH_OK;
+}
+
+// ---- CostasLoop / MuellerMullerTED banks ------------------------------------------------------------------------------
+struct wh_costas_bank {
+    int C;
+    double kp, ki, maxf;
+    CostasState *d_st = nullptr;
+};
+
+extern "C" int wh_costas_bank_create(wh_costas_bank **out, int C, double kp, double ki, double max_freq) {
+    if (!out || C < 1 || !(max_freq >= 0.0)) return set_err(WH_E_ARG, "wh_costas_bank_create: bad arguments");
+    wh_costas_bank *b = new wh_costas_bank();
+    std::unique_ptr<wh_costas_bank, void (*)(wh_costas_bank *)> guard(b, wh_costas_bank_destroy);
+    b->C = C; b->kp = kp; b->ki = ki; b->maxf = max_freq;
+    WH_HIP(hipMalloc(&b->d_st, (size_t)C * sizeof(CostasState)));
+    WH_HIP(hipMemset(b->d_st, 0, (size_t)C * sizeof(CostasState)));
+    *out = guard.release();
+    return WH_OK;
+}
+
+extern "C" void wh_costas_bank_destroy(wh_costas_bank *b) {
+    if (!b) return;
+    (void)hipFree(b->d_st);
+    delete b;
+}
+
+extern "C" int wh_costas_bank_reset(wh_costas_bank *b, void *stream) {
+    if (!b) return set_err(WH_E_ARG, "wh_costas_bank_reset: null handle");
+    WH_HIP(hipMemsetAsync(b->d_st, 0, (size_t)b->C * sizeof(CostasState), as_stream(stream)));
+    return WH_OK;
+}
+
+extern "C" int wh_costas_bank_run(wh_costas_bank *b, const double *d_x, size_t n, size_t stride, double *d_out,
+                                  double *h_freq, void *stream) {
+    if (!b) return set_err(WH_E_ARG, "wh_costas_bank_run: null handle");
+    hipStream_t st = as_stream(stream);
+    if (n > 0) {
+        if (!d_x || !d_out || stride < n || n > 0x7fffffff) return set_err(WH_E_ARG, "wh_costas_bank_run: bad buffers");
+        hipLaunchKernelGGL(k_costas, dim3((unsigned)b->C), dim3(64), 0, st, reinterpret_cast<const double2 *>(d_x), stride,
+                           (int)n, b->d_st, b->kp, b->ki, b->maxf, reinterpret_cast<double2 *>(d_out), stride);
+        WH_LAUNCH_CHECK();
+    }
+    if (h_freq) {   // frequency_offset property: synchronous read-back of the loop integrators
+        std::vector<CostasState> h((size_t)b->C);
+        WH_HIP(hipMemcpyAsync(h.data(), b->d_st, h.size() * sizeof(CostasState), hipMemcpyDeviceToHost, st));
+        WH_HIP(hipStreamSynchronize(st));
+        for (int c = 0; c < b->C; ++c) h_freq[c] = h[c].freq;
+    }
+    return WH_OK;
+}
+
+struct wh_mm_bank {
+    int C;
+    double sps, kp, ki;
+    MmState *d_st = nullptr;
+};
+
+extern "C" int wh_mm_bank_create(wh_mm_bank **out, int C, double sps, double kp, double ki) {
+    if (!out || C < 1 || !(sps > 1.0)) return set_err(WH_E_ARG, "wh_mm_bank_create: bad arguments");
+    wh_mm_bank *b = new wh_mm_bank();
+    std::unique_ptr<wh_mm_bank, void (*)(wh_mm_bank *)> guard(b, wh_mm_bank_destroy);
+    b->C = C; b->sps = sps; b->kp = kp; b->ki = ki;
+    WH_HIP(hipMalloc(&b->d_st, (size_t)C * sizeof(MmState)));
+    WH_HIP(hipMemset(b->d_st, 0, (size_t)C * sizeof(MmState)));
+    *out = guard.release();
+    return WH_OK;
+}
+
+extern "C" void wh_mm_bank_destroy(wh_mm_bank *b) {
+    if (!b) return;
+    (void)hipFree(b->d_st);
+    delete b;
+}
+
+extern "C" int wh_mm_bank_reset(wh_mm_bank *b, void *stream) {
+    if (!b) return set_err(WH_E_ARG, "wh_mm_bank_reset: null handle");
+    WH_HIP(hipMemsetAsync(b->d_st, 0, (size_t)b->C * sizeof(MmState), as_stream(stream)));
+    return WH_OK;
+}
+
+extern "C" int wh_mm_bank_run(wh_mm_bank *b, const double *d_x, size_t n, size_t stride, double *d_symbols,
+                              double *d_decisions, double *d_errors, size_t cap, int32_t *d_counts, void *stream) {
+    if (!b || !d_counts) return set_err(WH_E_ARG, "wh_mm_bank_run: null handle/counts");
+    hipStream_t st = as_stream(stream);
+    if (n == 0) {
+        WH_HIP(hipMemsetAsync(d_counts, 0, (size_t)b->C * sizeof(int32_t), st));
+        return WH_OK;
+    }
+    if (!d_x || !d_symbols || !d_decisions || !d_errors || stride < n || n > 0x7fffffff)
+        return set_err(WH_E_ARG, "wh_mm_bank_run: bad buffers");
+    if (cap < (size_t)(n / (size_t)(b->sps * 0.5)) + 2) return set_err(WH_E_ARG, "wh_mm_bank_run: cap too small");
+    hipLaunchKernelGGL(k_mm, dim3((unsigned)b->C), dim3(64), 0, st, reinterpret_cast<const double2 *>(d_x), stride, (int)n,
+                       b->d_st, b->sps, b->kp, b->ki, reinterpret_cast<double2 *>(d_symbols),
+                       reinterpret_cast<double2 *>(d_decisions), d_errors, cap, d_counts);
     WH_LAUNCH_CHECK();
     return WH_OK;
 }

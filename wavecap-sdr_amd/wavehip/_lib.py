@@ -108,6 +108,14 @@ PROTOTYPES = {
     "wh_pfb_reset": (c_int, [c_void_p, c_void_p]),
     "wh_pfb_get_history": (c_int, [c_void_p, c_void_p, c_void_p]),
     "wh_pfb_set_history": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "wh_costas_bank_create": (c_int, [C.POINTER(c_void_p), c_int, c_double, c_double, c_double]),
+    "wh_costas_bank_run": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "wh_costas_bank_reset": (c_int, [c_void_p, c_void_p]),
+    "wh_costas_bank_destroy": (None, [c_void_p]),
+    "wh_mm_bank_create": (c_int, [C.POINTER(c_void_p), c_int, c_double, c_double, c_double]),
+    "wh_mm_bank_run": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "wh_mm_bank_reset": (c_int, [c_void_p, c_void_p]),
+    "wh_mm_bank_destroy": (None, [c_void_p]),
     "wh_pfb_run_stats": (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_void_p, c_int, c_void_p]),
     "wh_stats_merge": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "wh_pfb_tune": (c_int, [c_void_p, c_int, c_int]),

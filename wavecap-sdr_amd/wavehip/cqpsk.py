@@ -177,3 +177,126 @@ class GardnerTED:
         s, e, c = self._bank.process_device(torch.from_numpy(x[None, :]).cuda())
         k = int(c[0])
         return s[0, :k].cpu().numpy(), e[0, :k].cpu().numpy()
+
+
+class CostasBank:
+    """CostasLoop (cqpsk.py:84-196) for C channels at once: complex128 [C, n] in -> phase-corrected complex128 [C, n]."""
+
+    def __init__(self, n_channels: int, loop_bw: float = 0.01, damping: float = 0.707, max_freq: float = 0.1):
+        self._torch = _lib.require_gpu()
+        self.n_channels = int(n_channels)
+        self._kp, self._ki = calculate_loop_coefficients(0.0, loop_bw, damping)     # cqpsk.py:107-110
+        self._max_freq = max_freq
+        self._h = C.c_void_p()
+        self._destroy = _lib.lib.wh_costas_bank_destroy
+        _lib.check(_lib.lib.wh_costas_bank_create(C.byref(self._h), self.n_channels, self._kp, self._ki, float(max_freq)),
+                   "wh_costas_bank_create")
+
+    def __del__(self):
+        h, destroy = getattr(self, "_h", None), getattr(self, "_destroy", None)
+        if h and destroy:
+            destroy(h)
+            self._h = None
+
+    def reset(self) -> None:
+        _lib.check(_lib.lib.wh_costas_bank_reset(self._h, _lib.stream_ptr(self._torch)), "wh_costas_bank_reset")
+
+    def process_device(self, x_dev):
+        torch = self._torch
+        assert x_dev.is_cuda and x_dev.dtype == torch.complex128 and x_dev.dim() == 2 and x_dev.shape[0] == self.n_channels
+        x_dev = x_dev.contiguous()
+        out = torch.empty_like(x_dev)
+        _lib.check(_lib.lib.wh_costas_bank_run(self._h, x_dev.data_ptr(), x_dev.shape[1], x_dev.shape[1], out.data_ptr(),
+                                               None, _lib.stream_ptr(torch)), "wh_costas_bank_run")
+        return out
+
+    def frequency_offsets(self) -> np.ndarray:
+        f = np.zeros(self.n_channels, dtype=np.float64)
+        _lib.check(_lib.lib.wh_costas_bank_run(self._h, None, 0, 0, None, f.ctypes.data, _lib.stream_ptr(self._torch)),
+                   "wh_costas_bank_run")
+        return f
+
+
+class CostasLoop:
+    """Single-channel drop-in for cqpsk.py:84-196: `process(sample)`, `process_block(samples) -> complex128`,
+    `reset()`, `frequency_offset`."""
+
+    def __init__(self, loop_bw: float = 0.01, damping: float = 0.707, max_freq: float = 0.1):
+        self._bank = CostasBank(1, loop_bw, damping, max_freq)
+        self._kp, self._ki, self._max_freq = self._bank._kp, self._bank._ki, max_freq
+
+    def reset(self) -> None:
+        self._bank.reset()
+
+    def process_block(self, samples):
+        x = np.ascontiguousarray(samples, dtype=np.complex128)
+        if x.size == 0:
+            return np.zeros(0, dtype=np.complex128)
+        torch = self._bank._torch
+        return self._bank.process_device(torch.from_numpy(x[None, :]).cuda())[0].cpu().numpy()
+
+    def process(self, sample: complex) -> complex:
+        return complex(self.process_block(np.array([sample], dtype=np.complex128))[0])
+
+    @property
+    def frequency_offset(self) -> float:
+        return float(self._bank.frequency_offsets()[0])
+
+
+class MuellerMullerBank:
+    """MuellerMullerTED (symbol_timing.py:214-380) for C channels: complex128 [C, n] -> (symbols, decisions complex128
+    [C, cap], errors float64 [C, cap], counts int32 [C]) on the GPU."""
+
+    def __init__(self, n_channels: int, samples_per_symbol: float, loop_bw: float = 0.01, damping: float = 1.0):
+        self._torch = _lib.require_gpu()
+        self.n_channels = int(n_channels)
+        self.samples_per_symbol = samples_per_symbol
+        self._kp, self._ki = calculate_loop_coefficients(samples_per_symbol, loop_bw, damping)
+        self._h = C.c_void_p()
+        self._destroy = _lib.lib.wh_mm_bank_destroy
+        _lib.check(_lib.lib.wh_mm_bank_create(C.byref(self._h), self.n_channels, float(samples_per_symbol), self._kp, self._ki),
+                   "wh_mm_bank_create")
+
+    def __del__(self):
+        h, destroy = getattr(self, "_h", None), getattr(self, "_destroy", None)
+        if h and destroy:
+            destroy(h)
+            self._h = None
+
+    def reset(self) -> None:
+        _lib.check(_lib.lib.wh_mm_bank_reset(self._h, _lib.stream_ptr(self._torch)), "wh_mm_bank_reset")
+
+    def process_device(self, x_dev):
+        torch = self._torch
+        assert x_dev.is_cuda and x_dev.dtype == torch.complex128 and x_dev.dim() == 2 and x_dev.shape[0] == self.n_channels
+        x_dev = x_dev.contiguous()
+        n = x_dev.shape[1]
+        cap = int(n / (self.samples_per_symbol * 0.5)) + 4
+        sym = torch.empty((self.n_channels, cap), dtype=torch.complex128, device=x_dev.device)
+        dec = torch.empty((self.n_channels, cap), dtype=torch.complex128, device=x_dev.device)
+        err = torch.empty((self.n_channels, cap), dtype=torch.float64, device=x_dev.device)
+        cnt = torch.zeros(self.n_channels, dtype=torch.int32, device=x_dev.device)
+        _lib.check(_lib.lib.wh_mm_bank_run(self._h, x_dev.data_ptr(), n, n, sym.data_ptr(), dec.data_ptr(), err.data_ptr(), cap,
+                                           cnt.data_ptr(), _lib.stream_ptr(torch)), "wh_mm_bank_run")
+        return sym, dec, err, cnt
+
+
+class MuellerMullerTED:
+    """Single-channel drop-in for symbol_timing.py:214-380: `process_block(samples) -> (symbols, decisions, errors)`."""
+
+    def __init__(self, samples_per_symbol: float, loop_bw: float = 0.01, damping: float = 1.0):
+        self.samples_per_symbol = samples_per_symbol
+        self._bank = MuellerMullerBank(1, samples_per_symbol, loop_bw, damping)
+        self._kp, self._ki = self._bank._kp, self._bank._ki
+
+    def reset(self) -> None:
+        self._bank.reset()
+
+    def process_block(self, samples):
+        x = np.ascontiguousarray(samples, dtype=np.complex128)
+        if x.size == 0:
+            return np.zeros(0, np.complex128), np.zeros(0, np.complex128), np.zeros(0, np.float64)
+        torch = self._bank._torch
+        s, d, e, c = self._bank.process_device(torch.from_numpy(x[None, :]).cuda())
+        k = int(c[0])
+        return s[0, :k].cpu().numpy(), d[0, :k].cpu().numpy(), e[0, :k].cpu().numpy()
