@@ -105,14 +105,20 @@ def cpu_baseline(seconds_budget: float = 8.0):
             el3 = time.perf_counter() - t1
         assert got == hops
         scaling.append({"cores": 3, "workers": "ThreadPoolExecutor(3) over hop ranges", "input_msps": round(n / el3 / 1e6, 2)})
-        nc = os.cpu_count() or 1
+        # all the cores this process may use (the scheduler affinity, not the machine's os.cpu_count(): a one-GPU box is a
+        # 16-core share of a 256-thread host), one worker process per core, a hop range of >= 128 hops each
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        nc = max(1, min(avail, hops // 128))
         with ProcessPoolExecutor(nc, mp_context=multiprocessing.get_context("fork")) as ex:   # forked before any GPU use
             list(ex.map(_cpu_pfb_worker, ranges(nc)))          # start the workers (imports) outside the timed pass
             t1 = time.perf_counter()
             got = sum(r[0] for r in ex.map(_cpu_pfb_worker, ranges(nc)))
             elc = time.perf_counter() - t1
         assert got == hops
-        scaling.append({"cores": nc, "workers": f"{nc} processes over hop ranges (os.cpu_count())",
+        scaling.append({"cores": nc, "workers": f"{nc} processes over hop ranges (sched_getaffinity: {avail}, os.cpu_count(): {os.cpu_count()})",
                         "input_msps": round(n / elc / 1e6, 2)})
     except Exception as e:      # the side measurements never take the bench line down
         scaling.append({"error": f"{type(e).__name__}: {e}"})

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run-kernel (4 | M, 64 <= M <= 512) vs the one-workgroup-per-hop generic kernel: same numbers? how much faster?
-Diagnostics only (WH_PFB_NO_RUN=1 at create time selects the generic kernel)."""
+Diagnostics only (tune(path=...) selects the kernel)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "wavecap-sdr_amd")]
@@ -11,13 +11,7 @@ CASES = ((8_000_000, 25_000), (2_400_000, 12_500), (6_000_000, 12_500), (2_400_0
 
 
 def make(fs, bw, run):
-    if run:
-        os.environ.pop("WH_PFB_NO_RUN", None)
-    else:
-        os.environ["WH_PFB_NO_RUN"] = "1"
-    ch = wavehip.PolyphaseChannelizer(fs, bw)
-    os.environ.pop("WH_PFB_NO_RUN", None)
-    return ch
+    return wavehip.PolyphaseChannelizer(fs, bw).tune(path="run" if run else "per_hop")
 
 
 for fs, bw in CASES:

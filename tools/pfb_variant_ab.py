@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""1024-channel filterbank: WH_PFB_VARIANT=1 (register prefetch) vs 3 (LDS-DMA prefetch, counted waits): same outputs?
+"""1024-channel filterbank: tune(prefetch=1) (register prefetch) vs 3 (LDS-DMA prefetch, counted waits): same outputs?
 kernel time (HIP events) interleaved in one process; cf32 and int16 input.  Diagnostics."""
 import os, sys, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,10 +9,8 @@ n = 1 << int(os.environ.get("LOG2N", "28"))
 x = torch.view_as_complex(torch.randn(n, 2, device="cuda").mul_(0.5))
 x16 = torch.randint(-20000, 20000, (2 * n,), dtype=torch.int16, device="cuda")
 chs = []
-for v in ("1", "3"):
-    os.environ["WH_PFB_VARIANT"] = v
-    ch = wavehip.PolyphaseChannelizer(10_000_000, 9765); ch.profile(True); chs.append(ch)
-os.environ.pop("WH_PFB_VARIANT")
+for v in (1, 3):
+    ch = wavehip.PolyphaseChannelizer(10_000_000, 9765).tune(prefetch=v); ch.profile(True); chs.append(ch)
 out = [torch.empty((chs[0].hops(n), 1024), dtype=torch.complex64, device="cuda") for _ in chs]
 for name, inp in (("cf32", x), ("int16", x16)):
     t = [[], []]
