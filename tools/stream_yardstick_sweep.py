@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""wh_diag_stream_1r2w variants (WH_DIAG_MODE, WH_DIAG_BLOCKS): which plain streaming kernel is the right yardstick."""
+"""wh_diag_stream_1r2w variants (WH_DIAG_MODE, WH_DIAG_BLOCKS -- read by a library built with `make DIAG=1` only): which plain
+streaming kernel is the right yardstick."""
 import os, sys, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "wavecap-sdr_amd")]
