@@ -91,6 +91,27 @@ def test_lsm_bank_64_channels_bit_identical_to_oracle():
     assert np.array_equal(again[3], fresh)
 
 
+def test_lsm_bank_lane_form_equals_wave_form():
+    """Beyond 2048 channels the feedback kernel runs one LANE per channel instead of one wave (lsm.hip): same arithmetic, so
+    a 2112-channel bank (33 copies of 64 streams) returns, channel by channel, exactly what the 64-channel bank -- pinned to
+    the oracle above -- returns, over three calls with carried state."""
+    import wavehip
+
+    fs, sr, n, C, reps = 48000, 4800, 9000, 64, 33
+    xs = np.stack([S.dqpsk_iq(n, fs, 2100 + c, symbol_rate=sr, snr_db=10.0 + (c % 10) * 2,
+                              freq_offset_hz=(c - 32) * 3.0)[0] for c in range(C)])
+    small = wavehip.LSMBank(C, fs, sr, max_samples_per_call=4096)
+    big = wavehip.LSMBank(C * reps, fs, sr, max_samples_per_call=4096)
+    xb = np.tile(xs, (reps, 1))
+    for lo, hi in ((0, 3000), (3000, 3050), (3050, 7000)):
+        d0, p0 = small.demodulate(xs[:, lo:hi], want_phases=True)
+        d1, p1 = big.demodulate(xb[:, lo:hi], want_phases=True)
+        for c in range(C * reps):
+            assert np.array_equal(d1[c], d0[c % C]), (c, lo)
+            assert p1[c].tobytes() == p0[c % C].tobytes(), (c, lo)
+    assert big.state(C * reps - 1) == small.state(C - 1)
+
+
 def test_lsm_edges():
     import wavehip
 

@@ -872,8 +872,7 @@ SHAPED = [(M * 25_000, 25_000, M) for M in (64, 80, 96, 128, 160, 192, 240, 256,
                                              1280, 2048, 4096)]
 
 
-@pytest.mark.parametrize("fs,bw,M", SHAPED)
-def test_a7_pfb_shaped_kernel(wh, O, fs, bw, M):
+def _shaped_kernel_checks(wh, O, fs, bw, M, T=9):
     """Channel counts with a kernel shaped at compile time (pfb_mid.hip; M = 320 is benchmark_dsp.py's shape): one launch
     per call does the head hops (carried history), the runs and the history update.  Checked (i) against the oracle over
     ragged calls (head only; one short run; many runs with a partial last one) to 1e-5, history bit-exact; (ii) against
@@ -882,10 +881,10 @@ def test_a7_pfb_shaped_kernel(wh, O, fs, bw, M):
     unpack first, bit for bit."""
     import torch
 
-    ch = wh.PolyphaseChannelizer(fs, bw)
-    hop = wh.PolyphaseChannelizer(fs, bw).tune(path="per_hop")
-    ref = O.PolyphaseChannelizer(fs, bw)
-    assert ch.channel_count == M
+    ch = wh.PolyphaseChannelizer(fs, bw, taps_per_channel=T).tune(path="shaped")
+    hop = wh.PolyphaseChannelizer(fs, bw, taps_per_channel=T).tune(path="per_hop")
+    ref = O.PolyphaseChannelizer(fs, bw, taps_per_channel=T)
+    assert ch.channel_count == M and ch.arms.shape == (M, T)
     big = M > 1024                      # fewer hops for the big shapes (the oracle is a Python loop per hop)
     x = S.noise_c64(M * (260 if big else 700) + 99, 4100 + M, amp=0.25)
     c1 = M * 3 + 1
@@ -904,10 +903,10 @@ def test_a7_pfb_shaped_kernel(wh, O, fs, bw, M):
         assert peak_rel_err(ya.cpu().numpy(), yb.cpu().numpy()) <= 2e-6, (M, lo, hi)
         assert np.array_equal(ch.arm_history, ref.arm_history)
         pieces.append(ya)
-    print(f"shaped M={M}: worst peak-relative error vs the oracle {worst:.2e}")
+    print(f"shaped M={M} T={T}: worst peak-relative error vs the oracle {worst:.2e}")
     # cut independence: a call that starts M/2 samples after the previous call's last hop continues the stream (its
     # history holds the stream's own blocks), so every hop must equal the one-call result bit for bit
-    one, two = wh.PolyphaseChannelizer(fs, bw), wh.PolyphaseChannelizer(fs, bw)
+    one, two = (wh.PolyphaseChannelizer(fs, bw, taps_per_channel=T) for _ in range(2))      # default dispatch
     HB, n_hops = M // 2, (400 if big else 900)
     xd = torch.from_numpy(x[: HB * (n_hops - 1) + M].copy()).cuda()
     whole = one.process_device(xd).clone()
@@ -921,17 +920,31 @@ def test_a7_pfb_shaped_kernel(wh, O, fs, bw, M):
     # int16 input
     i16 = S.pack_iq16_np(x[: M * 150 + 11])
     xq = torch.from_numpy(wh.unpack_iq16(i16)).cuda()
-    a, b = wh.PolyphaseChannelizer(fs, bw), wh.PolyphaseChannelizer(fs, bw)
+    a, b = (wh.PolyphaseChannelizer(fs, bw, taps_per_channel=T) for _ in range(2))
     ya = a.process_device(torch.from_numpy(i16.copy()).cuda())
     yb = b.process_device(xq)
     assert torch.equal(ya, yb) and np.array_equal(a.arm_history, b.arm_history)
 
 
+@pytest.mark.parametrize("fs,bw,M", SHAPED)
+def test_a7_pfb_shaped_kernel(wh, O, fs, bw, M):
+    _shaped_kernel_checks(wh, O, fs, bw, M)
+
+
+@pytest.mark.parametrize("M", [320, 1024])
+@pytest.mark.parametrize("T", [5, 7, 13, 17])
+def test_a7_pfb_shaped_kernel_other_arm_lengths(wh, O, M, T):
+    """The two headline channel counts at taps_per_channel 5, 7, 13, 17 (pfb_mid.hip WH_MID_CONFIGS_T): same checks as
+    at the default 9.  The oracle's filter design / filter code is generic in the arm length and pinned by the goldens
+    at 9 only (no reference fixture or call site uses another length)."""
+    _shaped_kernel_checks(wh, O, M * 25_000, 25_000, M, T)
+
+
 @pytest.mark.parametrize("fs,bw,M,T", [(8_000_000, 25_000, 320, 5), (8_000_000, 25_000, 320, 12),
                                         (10_000_000, 9765, 1024, 6), (2_400_000, 12_500, 192, 16)])
 def test_a7_pfb_other_tap_counts_vs_oracle(wh, O, fs, bw, M, T):
-    """taps_per_channel is a constructor argument of the reference (channelizer.py:39, default 9).  The fused and the
-    run kernel are built for 9 taps per arm; any other count takes the per-hop kernel -- same numbers as the oracle's
+    """taps_per_channel is a constructor argument of the reference (channelizer.py:39, default 9).  Counts without a
+    shaped instance (pfb_mid.hip: 9 everywhere, 5 / 7 / 13 / 17 at M = 320 and 1024) take the per-hop kernel -- same numbers as the oracle's
     restatement of the same design + filter code (pinned by the goldens at the default count), history carried across
     two calls."""
     ch = wh.PolyphaseChannelizer(fs, bw, taps_per_channel=T)

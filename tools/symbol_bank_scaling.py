@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where the sequential symbol kernels saturate: C4FM bank (one wave per channel in k_seq), Phase-2 CQPSK bank (one wave per
-channel in k_cq_seq) and LSM bank (one lane per channel) at 64 / 256 / 1024 / 4096 channels: time per call, x real time
+channel in k_cq_seq) and LSM bank (one wave per channel in k_lsm_seq) at 64 / 256 / 1024 / 4096 channels: time per call, x real time
 per channel and aggregate sample rate.  Diagnostics."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -9,9 +9,8 @@
 //                gain update, and the per-call NCO scalars;
 //   k_lsm_front  thread per output sample: scale, NCO rotation (complex128) staged once per tile in LDS,
 //                63-tap FIR accumulated in float64, cast to complex64 behind a 32-sample carried history;
-//   k_lsm_seq    ONE LANE PER CHANNEL for the feedback part; lanes stay aligned per SYMBOL (each lane
-//                fast-forwards its own clock to its next symbol instant, then all lanes of the wave do the
-//                interpolation / slicer / loop updates together);
+//   k_lsm_seq    ONE WAVE PER CHANNEL for the feedback part (uniform scalar loop; samples in a register window
+//                handed out by v_readlane, interpolator taps in LDS); one LANE per channel beyond 2048 channels;
 //   k_lsm_carry  saves the last 32 filtered samples for the next call.
 #include "wh_common.h"
 #include "wh_portable_math.h"
@@ -147,15 +146,32 @@ __global__ __launch_bounds__(TILE) void k_lsm_front(LsmArgs a) {
     y[NT + i] = o;
 }
 
-__device__ __forceinline__ float2 lsm_interp(const float *mmse, const float2 *ynew, int so, int imu) {
-    // ynew points at the newest sample; offsets count back in time; offsets < 0 are skipped (p25.py:350)
+// The wave-per-channel form of the feedback kernel reads its samples from a REGISTER WINDOW instead of memory: lane l
+// holds P = y[base - 64 + l] and Q = y[base + l] (two coalesced 512-byte loads per 64 samples); sample idx comes out by
+// v_readlane with a wave-uniform lane number.  The look-back of the interpolators is < 32 samples, so two chunks suffice.
+struct LsmWin {
+    float2 P, Q;
+    int base;   // sample index of Q's lane 0 (multiple of 64, relative to the call's first sample; may be negative)
+};
+__device__ __forceinline__ float2 lsm_win_get(const LsmWin &w, int idx) {   // idx wave-uniform, base - 64 <= idx < base + 64
+    const int r = idx - w.base;                  // -64 .. 63
+    const int ln = __builtin_amdgcn_readfirstlane(r & 63);
+    const float2 src = __builtin_amdgcn_readfirstlane(r) >= 0 ? w.Q : w.P;
+    return make_float2(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(src.x), ln)),
+                       __int_as_float(__builtin_amdgcn_readlane(__float_as_int(src.y), ln)));
+}
+// 8-tap MMSE interpolator at look-back `so` from the newest sample; offsets count back in time, offsets < 0 are skipped
+// (p25.py:350).  Operands come from the window / the LDS tap table; products and sums in the reference's order.
+// WAVE = false: one LANE per channel, samples straight from memory (y), taps from the global table.
+template <bool WAVE>
+__device__ __forceinline__ float2 lsm_interp(const float *mmse, const LsmWin &w, const float2 *y, int inew, int so, int imu) {
     float ar = 0.0f, ai = 0.0f;
 #pragma unroll
     for (int tap = 0; tap < 8; ++tap) {
         int off = so + tap - 3;
         if (off < 0 || off >= NT) continue;
         float t = mmse[imu * 8 + tap];
-        float2 v = ynew[-off];
+        float2 v = WAVE ? lsm_win_get(w, inew - off) : y[inew - off];
         float pr = __fsub_rn(__fmul_rn(t, v.x), __fmul_rn(0.0f, v.y));  // (t + 0j) * (a + bj)
         float pi = __fadd_rn(__fmul_rn(t, v.y), __fmul_rn(0.0f, v.x));
         ar = __fadd_rn(ar, pr);
@@ -181,11 +197,37 @@ __device__ __forceinline__ float lsm_angle(float im, float re) {
     return whm_atan2f(im, re);
 }
 
+// ONE WAVE PER CHANNEL, every lane running the same scalar loop (round 2; one lane per channel before): the loop waits on
+// its own samples -- 24 dependent loads per symbol whose addresses follow the symbol clock (3.2 us per symbol, all of it
+// memory latency) -- so the samples now sit in a register window (LsmWin) and the interpolator taps in LDS.  The
+// arithmetic is untouched (same functions, same order): outputs and carried state stay bit-identical to oracle/lsm_ref.c.
+//
+// WAVE = false is the one-LANE-per-channel form (64 channels per wave, samples from memory): 1.7x slower per call, but a
+// wave carries 64 channels, so beyond ~2000 channels -- where the wave form has filled every SIMD -- it has the higher
+// aggregate rate.  The launch picks by channel count; both forms run the same arithmetic.
+template <bool WAVE>
 __global__ __launch_bounds__(64) void k_lsm_seq(LsmArgs a) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= a.C) return;
+    __shared__ float mmse_s[WAVE ? 129 * 8 : 1];
+    const int lane = threadIdx.x;
+    const int c = WAVE ? (int)blockIdx.x : (int)(blockIdx.x * 64 + threadIdx.x);
+    const bool writer = WAVE ? lane == 0 : true;
+    const float *mmse = a.mmse;
+    if constexpr (WAVE) {
+        for (int j = lane; j < 129 * 8; j += 64) mmse_s[j] = a.mmse[j];
+        __syncthreads();
+        mmse = mmse_s;
+    } else {
+        if (c >= a.C) return;
+    }
     LsmState S = a.st[c];
     const float2 *y = a.filt + (size_t)c * (NT + a.n_max) + NT;
+    // window: Q = samples [0, 64), P = the 64 before (the carried history covers -32 .. -1; older ones are never read)
+    LsmWin w;
+    w.base = 0;
+    if constexpr (WAVE) {
+        w.P = lane >= 64 - NT ? y[lane - 64] : make_float2(0.f, 0.f);
+        w.Q = lane < a.n ? y[lane] : make_float2(0.f, 0.f);
+    }
     uint8_t *dib = a.dibits + (size_t)c * a.cap;
     float *pho = a.phases ? a.phases + (size_t)c * a.cap : nullptr;
     const double PI_D = 3.141592653589793;
@@ -210,7 +252,14 @@ __global__ __launch_bounds__(64) void k_lsm_seq(LsmArgs a) {
             }
         }
         if (!fire) break;
-        const float2 *yn = y + (i - 1);
+        const int inew = (WAVE ? __builtin_amdgcn_readfirstlane(i) : i) - 1;   // newest sample of this symbol
+        if constexpr (WAVE) {
+            while (inew >= w.base + 64) {                              // slide the register window
+                w.P = w.Q;
+                w.base += 64;
+                w.Q = w.base + lane < a.n ? y[w.base + lane] : make_float2(0.f, 0.f);
+            }
+        }
         int imu;
         if (!S.f32mode) {
             S.clock64 = __dsub_rn(S.clock64, 1.0);
@@ -227,7 +276,7 @@ __global__ __launch_bounds__(64) void k_lsm_seq(LsmArgs a) {
         }
         if (imu > 128) imu = 128;
         if (imu < 0) imu = 0;  // NaN clock
-        float2 curr = lsm_interp(a.mmse, yn, 0, imu);
+        float2 curr = lsm_interp<WAVE>(mmse, w, y, inew, 0, imu);
         float curr_mag = whm_hypotf(curr.x, curr.y);
         int dibit;
         float phase_out;
@@ -274,14 +323,14 @@ __global__ __launch_bounds__(64) void k_lsm_seq(LsmArgs a) {
         }
         if (S.freq_offset < -0.02) S.freq_offset = -0.02;
         if (S.freq_offset > 0.02) S.freq_offset = 0.02;
-        if ((size_t)count < a.cap) {
+        if ((size_t)count < a.cap && writer) {
             dib[count] = (uint8_t)dibit;
             if (pho) pho[count] = phase_out;
         }
         ++count;
         if (a.gardner) {
-            float2 mid = lsm_interp(a.mmse, yn, a.half_sps, imu);
-            float2 ps = lsm_interp(a.mmse, yn, a.full_sps, imu);
+            float2 mid = lsm_interp<WAVE>(mmse, w, y, inew, a.half_sps, imu);
+            float2 ps = lsm_interp<WAVE>(mmse, w, y, inew, a.full_sps, imu);
             float er = __fsub_rn(curr.x, ps.x), ei = __fsub_rn(curr.y, ps.y);
             float ted = __fsub_rn(__fmul_rn(er, mid.x), __fmul_rn(ei, -mid.y));
             float step = __fmul_rn(0.015f, ted);
@@ -306,8 +355,10 @@ __global__ __launch_bounds__(64) void k_lsm_seq(LsmArgs a) {
         S.prev_im = curr.y;
         S.first = 0;
     }
-    a.st[c] = S;
-    a.counts[c] = count;
+    if (writer) {
+        a.st[c] = S;
+        a.counts[c] = count;
+    }
 }
 
 __global__ void k_lsm_carry(LsmArgs a) {
@@ -318,6 +369,9 @@ __global__ void k_lsm_carry(LsmArgs a) {
 }
 
 }  // namespace
+
+// measured crossover of the two k_lsm_seq forms (tools/symbol_bank_scaling.py: 1024 ch 12.5 ms, 4096 ch 24.5 vs 15.6 ms)
+static constexpr int LSM_WAVE_FORM_MAX_CHANNELS = 2048;
 
 struct wh_lsm_bank {
     int C, n_max;
@@ -417,7 +471,10 @@ extern "C" int wh_lsm_bank_run(wh_lsm_bank *b, const float *d_iq, size_t n, size
     WH_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_lsm_front, dim3((unsigned)((n + TILE - 1) / TILE), b->C), dim3(TILE), 0, st, a);
     WH_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_lsm_seq, dim3((b->C + 63) / 64), dim3(64), 0, st, a);
+    if (b->C <= LSM_WAVE_FORM_MAX_CHANNELS)
+        hipLaunchKernelGGL(k_lsm_seq<true>, dim3(b->C), dim3(64), 0, st, a);
+    else
+        hipLaunchKernelGGL(k_lsm_seq<false>, dim3((b->C + 63) / 64), dim3(64), 0, st, a);
     WH_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_lsm_carry, dim3((b->C * NT + 255) / 256), dim3(256), 0, st, a);
     WH_LAUNCH_CHECK();

@@ -916,7 +916,24 @@ extern "C" void wh_diag_mid_stamps(long long *d_buf, int wg) { g_diag_stamps = d
 
 namespace wh {
 
+// Other arm lengths (taps_per_channel != 9; every reference call site uses the default 9, the constructor takes any):
+// the two headline channel counts at T = 5, 7, 13, 17.  The arm windows are T + GH - 1 registers per quad element, so
+// the long arms run at 2 waves per SIMD and keep only part of their taps in registers.
+//        M     T  R GH NWF WPE PB PADN IMGX TREG LSP
+#define WH_MID_CONFIGS_T(X) \
+    X(320, 5, 3, 4, 0, 3, 20, 1, 0, 20, 0) \
+    X(320, 7, 3, 4, 0, 3, 20, 1, 0, 28, 0) \
+    X(320, 13, 3, 4, 0, 2, 20, 1, 0, 36, 0) \
+    X(320, 17, 3, 4, 0, 2, 20, 1, 0, 20, 0) \
+    X(1024, 5, 1, 4, 0, 3, 16, 2, 0, 20, 0) \
+    X(1024, 7, 1, 4, 0, 3, 16, 2, 0, 28, 0) \
+    X(1024, 13, 1, 4, 0, 2, 16, 2, 0, 36, 0) \
+    X(1024, 17, 1, 4, 0, 2, 16, 2, 0, 36, 0)
+
 bool pfb_mid_supported(int M, int T) {
+#define X(M_, T_, R_, GH_, NWF_, WPE_, PB_, PADN_, IMGX_, TREG_, LSP_) if (M == M_ && T == T_) return true;
+    WH_MID_CONFIGS_T(X)
+#undef X
     if (T != 9) return false;
 #define X(M_, R_, GH_, NWF_, WPE_, PB_, PADN_, IMGX_, TREG_, LSP_) if (M == M_) return true;
     WH_MID_CONFIGS(X)
@@ -931,6 +948,10 @@ int pfb_mid_launch(int M, int T, const PfbMidCall &c, hipStream_t st, long long 
         WH_MID_CONFIGS(X)
 #undef X
     }
+#define X(M_, T_, R_, GH_, NWF_, WPE_, PB_, PADN_, IMGX_, TREG_, LSP_) \
+    if (M == M_ && T == T_) return mid_launch_t<MidCfg<M_, T_, R_, GH_, NWF_, WPE_, PB_, PADN_, IMGX_, TREG_, LSP_>>(c, st, grid_out);
+    WH_MID_CONFIGS_T(X)
+#undef X
     return set_err(WH_E_ARG, "pfb_mid_launch: no instance for M=%d T=%d", M, T);
 }
 
