@@ -219,6 +219,9 @@ typedef struct wh_spectrum wh_spectrum;
 int wh_spectrum_create(wh_spectrum **out, int fft_size);
 int wh_spectrum_run(wh_spectrum *s, const float *d_iq, size_t n_frames, size_t frame_stride,
                     float *d_power_db, void *stream);
+/* Explicit kernel selection for tests / measurements: key 1, value 0 auto (default), 1 the Stockham / direct-DFT kernel,
+ * 2 the shaped kernel (fft_size 256 .. 4096; WH_E_ARG when the size has none). */
+int wh_spectrum_tune(wh_spectrum *s, int key, int value);
 /* rocFFT engine: window prologue -> (rocFFT C2C forward of length fft_size, batched, run by the caller's
  * binding) -> |X| / fftshift / 20 log10 epilogue.  d_windowed, d_fft: complex64 [n_frames][fft_size]. */
 int wh_spectrum_window(wh_spectrum *s, const float *d_iq, size_t n_frames, size_t frame_stride,

@@ -322,12 +322,15 @@ def test_a7_pfb_int16_input(wh):
         assert np.array_equal(a.arm_history, b.arm_history)
 
 
-def test_a8_spectrum(wh, golden):
+@pytest.mark.parametrize("engine", ["fused", "stockham"])
+def test_a8_spectrum(wh, golden, engine):
+    """engine "fused" = the library's choice (the shaped kernel at the goldens' sizes 512 .. 4096); "stockham" = the
+    kernel serving the other power-of-two sizes, forced."""
     g = golden("a8_spectrum")
     for ci in range(int(g["n_cases"])):
         N, fs, seed = (int(v) for v in g[f"c{ci}_args"])
         iq = S.fm_tone_c64(N + 100, fs, seed=seed, deviation=20000.0, carrier_hz=123456.0, noise_amp=0.01)
-        be = wh.HipFFTBackend(N)
+        be = wh.HipFFTBackend(N, engine=engine)
         r = be.execute(iq, fs)
         assert be.name == "hip" and r.power_db.dtype == np.float32 and r.freqs.dtype == np.float32
         ref = g[f"c{ci}_power"]
@@ -348,6 +351,51 @@ def test_a8_spectrum(wh, golden):
     assert peak_rel_err(10.0 ** (r.power_db / 20.0), 10.0 ** (p / 20.0)) <= TOL
 
 
+@pytest.mark.parametrize("N", [256, 512, 1024, 2048, 4096])
+def test_a8_spectrum_shaped_kernel_batches(wh, O, N):
+    """The shaped spectrum kernel (pfb_mid.hip spectrum_mid_kernel) on batches: frame counts that do not fill the last
+    workgroup, overlapping frames (frame_stride < N) and strides > N; every frame equals the oracle to 1e-5 (linear
+    magnitude, peak-relative) and, bit for bit, the same frame run alone; a silent frame gives -200 dB; enough
+    frames for several rounds per workgroup (the prefetch path)."""
+    import torch
+
+    with pytest.raises(RuntimeError):
+        wh.HipFFTBackend(8192, engine="shaped")
+    be = wh.HipFFTBackend(N, engine="shaped")
+    x = S.fm_tone_c64(N * 40 + 777, 2_400_000, seed=3000 + N, deviation=30000.0, carrier_hz=-234567.0, noise_amp=0.02)
+    x[N * 20: N * 22] = 0
+    xd = torch.from_numpy(x).cuda()
+    worst = 0.0
+    for frames, stride in ((1, N), (3, N), (37, N), (13, N // 2 + 3), (9, 3 * N + 5)):
+        out = be.execute_device(xd, frames, stride).cpu().numpy()
+        for f in range(frames):
+            seg = x[f * stride: f * stride + N]
+            ref = O.spectrum(seg, 2_400_000, N)[0]
+            if not seg.any():
+                assert np.all(np.abs(out[f] + 200.0) <= 1e-4)       # 20 log10(0 + 1e-10)
+                continue
+            err = peak_rel_err(10.0 ** (out[f] / 20.0), 10.0 ** (ref / 20.0))
+            worst = max(worst, err)
+            assert err <= TOL, (N, frames, stride, f)
+            strong = ref > ref.max() - 60.0
+            assert np.max(np.abs(out[f][strong] - ref[strong])) <= 0.01
+        if frames > 5:
+            one = be.execute_device(xd[5 * stride: 5 * stride + N].contiguous(), 1)
+            assert np.array_equal(out[5], one[0].cpu().numpy())
+    print(f"spectrum shaped N={N}: worst peak-relative error {worst:.2e}")
+    # many rounds per workgroup: 3 x (CUs x resident workgroups) frame groups, compared with the Stockham kernel
+    frames = 20000 if N <= 1024 else 6000
+    g = torch.Generator(device="cuda").manual_seed(N)
+    big = torch.view_as_complex(torch.randn(frames * N, 2, device="cuda", generator=g) * 0.3)
+    a = be.execute_device(big, frames)
+    b = wh.HipFFTBackend(N, engine="stockham").execute_device(big, frames)
+    lin = lambda p: 10.0 ** (p.double() / 20.0)
+    assert ((lin(a) - lin(b)).abs().amax(1) / lin(b).amax(1)).max().item() <= TOL
+    pick = torch.tensor([0, 1, frames // 2, frames - 2, frames - 1], device="cuda")
+    for f in pick.tolist():
+        assert torch.equal(a[f], be.execute_device(big[f * N: (f + 1) * N].contiguous(), 1)[0])
+
+
 def test_a8_spectrum_rocfft_engine_and_batch(wh, golden, O):
     """The rocFFT engine (HIP window/epilogue kernels around a rocFFT batched C2C) gives the reference
     spectrum too, and batched frames equal frame-by-frame execution for both engines."""
@@ -365,7 +413,7 @@ def test_a8_spectrum_rocfft_engine_and_batch(wh, golden, O):
     N, frames = 2048, 4096
     x = torch.view_as_complex(torch.randn(frames * N, 2, device="cuda") * 0.3)
     outs = {}
-    for eng in ("fused", "rocfft"):
+    for eng in ("fused", "stockham", "rocfft"):
         be = wh.HipFFTBackend(N, engine=eng)
         outs[eng] = be.execute_device(x, frames)
         one = be.execute_device(x[5 * N: 6 * N].contiguous(), 1)

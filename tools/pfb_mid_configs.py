@@ -3,12 +3,20 @@
 M, enumerate (R runs per workgroup, GH hops per group, image padding) and score each by lane utilisation, LDS footprint
 and simulated LDS bank conflicts of the arm-MAC writes, the in-place passes and the last pass (bank rules of
 MI355X_MICROARCH.md: ds_read_b64 = 2 groups of 32 lanes over 64 banks, ds_write_b64 = 4 groups of 16 lanes over 32 banks).
-Mirrors MidCfg / pass_map / pos_of of pfb_mid.hip.   pfb_mid_configs.py M [M ...]"""
+Mirrors MidCfg / pass_map / pos_of of pfb_mid.hip.   pfb_mid_configs.py [--r8] M[:R] [M[:R] ...]"""
 import sys, itertools
+
+
+R8 = "--r8" in sys.argv      # radix-8 passes for the power-of-two part (MidCfg's R8_ parameter)
 
 
 def plan(Q):
     r, L, rem, cur = [], [], Q, Q
+    if R8:
+        k, q = 0, Q
+        while q % 2 == 0: q //= 2; k += 1
+        for _ in range(k // 3 - 1 if k % 3 == 1 else k // 3):
+            r.append(8); L.append(cur); cur //= 8; rem //= 8
     for rad in (4, 2, 3, 5):
         while rem > 1 and rem % rad == 0:
             r.append(rad); L.append(cur); cur //= rad; rem //= rad
@@ -137,7 +145,7 @@ def best(M, force_R=None):
         NT = R * Q
         NW = (NT + 63) // 64
         if NW > 16 or (not force_R and NT / (NW * 64) < 0.88): continue
-        for GH in (4, 3, 2, 5, 6, 8):
+        for GH in (4, 3, 2, 5, 6, 8, 1):
             for PB in pbs:
                 for PADN in ((0,) if PB == 0 else (1, 2)):
                     for IMGX in range(0, 5):
@@ -154,10 +162,11 @@ def best(M, force_R=None):
 
 
 if __name__ == "__main__":
-    for arg in sys.argv[1:]:
+    for arg in (a for a in sys.argv[1:] if not a.startswith("--")):
         M, fr = (int(v) for v in arg.split(":")) if ":" in arg else (int(arg), None)
         b = best(M, fr)
         if not b: print(f"M={M}: no workgroup-mode shape"); continue
         wpe = 3 if b["NW"] in (3, 4, 12) else 2
-        print(f"    X({M}, {b['R']}, {b['GH']}, 0, {wpe}, {b['PB']}, {b['PADN']}, {b['IMGX']}, 36, {b['LSP']}) \\   // plan {b['plan']} waves {b['NW']} lanes/hop {b['LS']} "
+        r8s = ", 1" if R8 else ""
+        print(f"    X({M}, {b['R']}, {b['GH']}, 0, {wpe}, {b['PB']}, {b['PADN']}, {b['IMGX']}, 36, {b['LSP']}{r8s}) \\   // plan {b['plan']} waves {b['NW']} lanes/hop {b['LS']} "
               f"util {b['util']:.2f} pass-util {b['putil']:.2f} last-pass lanes/hop {b['LSL']} LDS {b['lds']} B conflicts rd x{b['rd']:.2f} wr x{b['wr']:.2f}")

@@ -29,6 +29,19 @@ bool pfb_mid_supported(int M, int T);
 // one launch: head hops (carried history), the runs, and the history update.  Returns a WH_* status.  With grid_out
 // nothing is launched and the planned grid size is returned (the statistics workspace has one row per workgroup).
 int pfb_mid_launch(int M, int T, const PfbMidCall &c, hipStream_t st, long long *grid_out = nullptr);
+// spectrum frames (window -> FFT -> fftshift -> dB) through the shaped passes
+struct SpectrumMidCall {
+    const float2 *x;         // samples; frame f starts at x + f * frame_stride
+    size_t frame_stride;
+    long long n_frames;      // > 0
+    float *out;              // [n_frames][N] dB
+    float *sink;             // [N] scratch row nobody reads
+    const float *window;     // [N]
+    const float2 *tw;        // exp(-2 pi i m / N)
+    int cu_count;
+};
+bool spectrum_mid_supported(int N);
+int spectrum_mid_launch(int N, const SpectrumMidCall &c, hipStream_t st);
 // kernel name fragment for profiles / bench reporting
 const char *pfb_mid_kernel_name();
 

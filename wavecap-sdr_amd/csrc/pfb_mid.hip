@@ -17,6 +17,8 @@
 //     in-order LDS queue of one wave, no s_barrier), and the workgroup meets twice per group (images written / images
 //     free).  Channel counts whose hop does not fit a wave's share use all threads per pass with workgroup barriers.
 //   * all index arithmetic (butterfly -> image word, twiddle slot, digit reversal) folds into constants per M.
+// The same passes serve the spectrum frames of spectrum.hip (spectrum_mid_kernel below: a frame is an image, the last
+// pass writes dB at the fftshift-ed bin).
 // The first T-1 hops of a call read the carried history, where the half-block identity does not hold (after reset()
 // or an assigned arm_history): they are computed column by column by extra workgroups of the same launch, through the
 // same passes (so a hop's bits do not depend on where a stream is cut into calls); one more workgroup writes the
@@ -42,9 +44,23 @@ struct MidPlan {
     bool ok;
 };
 
-constexpr MidPlan mid_plan(int Q) {
+// r8: radix-8 passes for the power-of-two part (2^k -> as many 8s as leave no lone radix-2 pass: k = 3a -> a eights,
+// 3a + 2 -> a eights and a 4, 3a + 1 -> a - 1 eights and two 4s): a third fewer trips through LDS than radix 4.
+constexpr MidPlan mid_plan(int Q, bool r8 = false) {
     MidPlan p{};
     int rem = Q, L = Q, n = 0;
+    if (r8) {
+        int k = 0;
+        for (int q = Q; q % 2 == 0; q /= 2) ++k;
+        int n8 = k % 3 == 1 ? k / 3 - 1 : k / 3;
+        for (; n8 > 0; --n8) {
+            p.r[n] = 8;
+            p.L[n] = L;
+            L /= 8;
+            rem /= 8;
+            ++n;
+        }
+    }
     const int rad[4] = {4, 2, 3, 5};
     for (int ri = 0; ri < 4; ++ri)
         while (rem > 1 && rem % rad[ri] == 0 && n < 12) {
@@ -118,6 +134,24 @@ __device__ __forceinline__ void bfly(v2f (&v)[4]) {
     v[1] = WH_PMI(d02, d13);
     v[3] = WH_MMI(d02, d13);
 }
+__device__ __forceinline__ void bfly(v2f (&v)[8]) {
+    // even / odd halves through the radix-4 butterfly, then X[k] = E[k] + W8^k O[k], X[k + 4] = E[k] - W8^k O[k] with
+    // W8 = (1 - i) / sqrt 2, W8^2 = -i, W8^3 = -(1 + i) / sqrt 2
+    const float C = 0.70710678118654752440f;
+    v2f e[4] = {v[0], v[2], v[4], v[6]}, o[4] = {v[1], v[3], v[5], v[7]};
+    bfly(e);
+    bfly(o);
+    const v2f t1 = WH_PMI(o[1], o[1]);    // o1 - i o1 = sqrt 2 W8 o1
+    const v2f t3 = WH_MMI(o[3], o[3]);    // o3 + i o3 = -sqrt 2 W8^3 o3
+    v[0] = e[0] + o[0];
+    v[4] = e[0] - o[0];
+    v[1] = WH_FMA(t1, bc(C), e[1]);
+    v[5] = WH_FMA(t1, bc(-C), e[1]);
+    v[2] = WH_PMI(e[2], o[2]);
+    v[6] = WH_MMI(e[2], o[2]);
+    v[3] = WH_FMA(t3, bc(-C), e[3]);
+    v[7] = WH_FMA(t3, bc(C), e[3]);
+}
 __device__ __forceinline__ void bfly(v2f (&v)[5]) {
     const float C1 = 0.30901699437494742410f, S1 = 0.95105651629515357212f;    // cos, sin 2 pi / 5
     const float C2 = -0.80901699437494742410f, S2 = 0.58778525229247312917f;   // cos, sin 4 pi / 5
@@ -186,7 +220,7 @@ constexpr PassMap pass_map(int LS, int nblk, int m) {
 // layout: word p of a hop image sits at p + (p / PB) PADN (PB = 0: unpadded) and images are IMGS = ph(M) + IMGX words
 // apart -- chosen per M so that the pass reads / writes spread over the LDS banks; TREG of the quad's 4 T taps stay in
 // registers, the rest is re-read from LDS every group; LSP lanes per hop image in the workgroup-wide passes (0 = all).
-template <int M_, int T_, int R_, int GH_, int NWF_, int WPE_, int PB_, int PADN_, int IMGX_, int TREG_, int LSP_>
+template <int M_, int T_, int R_, int GH_, int NWF_, int WPE_, int PB_, int PADN_, int IMGX_, int TREG_, int LSP_, int R8_ = 0>
 struct MidCfg {
     static constexpr int M = M_, T = T_, R = R_, GH = GH_, NWF = NWF_, WPE = WPE_, PB = PB_, PADN = PADN_, TREG = TREG_;
     static constexpr int Q = M / 4, HB = M / 2, NT = R * Q, NW = (NT + 63) / 64, NIMG = R * GH;
@@ -197,7 +231,7 @@ struct MidCfg {
     // LSP_ lanes per hop image (0: as many as the quad threads give); fewer when the pass shapes need a rounder number
     static constexpr int TH = WAVE_MODE ? 64 : (LSP_ > 0 ? LSP_ : NT / NIMG) * NIMG;
     static constexpr int HPL = HPW;                   // images of a wave's last pass in wave mode
-    static constexpr MidPlan P = mid_plan(Q);
+    static constexpr MidPlan P = mid_plan(Q, R8_ != 0);   // R8_: radix-8 passes for the power-of-two part
     static constexpr int ph(int p) { return PB_ ? p + (p / PB_) * PADN_ : p; }
     static constexpr int IMGS = ph(M_) + IMGX_;
     static constexpr int NL4 = (4 * T - TREG + 3) / 4;   // float4 of LDS taps per quad
@@ -789,10 +823,14 @@ int g_diag_stamp_wg = 0;
 
 // (M, R, GH, NWF, WPE, PB, PADN, IMGX, TREG, LSP): see MidCfg
 #ifndef WH_MID_320
-#define WH_MID_320 3, 4, 0, 3, 20, 1, 0, 36, 0
+#define WH_MID_320 3, 4, 0, 3, 20, 1, 0, 36, 0, 0
 #endif
 #define WH_MID_X(X, ...) X(__VA_ARGS__)
-// Shapes found by tools/pfb_mid_configs.py (lane utilisation, LDS footprint, simulated bank conflicts):
+// Shapes found by tools/pfb_mid_configs.py (lane utilisation, LDS footprint, simulated bank conflicts).  Last column R8:
+// radix-8 passes for the power-of-two part (tools/pfb_mid_configs.py --r8) where fewer LDS passes measured faster
+// (2^26 samples: M = 2048 552 -> 446 us, 640 431 -> 399, 480 438 -> 409, 384 417 -> 406, 512 367 -> 356; no gain for
+// M <= 256, which run at the memory system's pace already; 768 / 800 / 1280 have no affine radix-8 shape at these
+// workgroup sizes, 4096 spills at its 128-register budget):
 //      64: plan [4, 4] waves 4 lanes/hop 4 util 1.00 pass-util 1.00 last-pass lanes/hop 16 LDS 35008 B conflicts rd x1.50 wr x1.00
 //      80: plan [4, 5] waves 4 lanes/hop 5 util 0.94 pass-util 0.94 last-pass lanes/hop 16 LDS 32880 B conflicts rd x2.90 wr x1.00
 //      96: plan [4, 2, 3] waves 4 lanes/hop 6 util 0.94 pass-util 0.94 last-pass lanes/hop 32 LDS 32976 B conflicts rd x1.66 wr x1.31
@@ -801,39 +839,39 @@ int g_diag_stamp_wg = 0;
 //     192: plan [4, 4, 3] waves 4 lanes/hop 12 util 0.94 pass-util 0.94 last-pass lanes/hop 64 LDS 33360 B conflicts rd x2.04 wr x1.31
 //     240: plan [4, 3, 5] waves 4 lanes/hop 10 util 0.94 pass-util 0.62 last-pass lanes/hop 16 LDS 32496 B conflicts rd x1.88 wr x1.58
 //     256: plan [4, 4, 4] waves 4 lanes/hop 16 util 1.00 pass-util 1.00 last-pass lanes/hop 64 LDS 37824 B conflicts rd x2.00 wr x1.33
-//     384: plan [4, 4, 2, 3] waves 8 lanes/hop 24 util 0.94 pass-util 0.94 last-pass lanes/hop 64 LDS 64208 B conflicts rd x1.95 wr x1.47
+//     384: plan [8, 4, 3] waves 8 lanes/hop 24 util 0.94 pass-util 0.94 last-pass lanes/hop 64 LDS 64848 B conflicts rd x1.96 wr x1.62
 //     400: plan [4, 5, 5] waves 5 lanes/hop 20 util 0.94 pass-util 0.75 last-pass lanes/hop 16 LDS 40304 B conflicts rd x1.62 wr x1.35
-//     480: plan [4, 2, 3, 5] waves 4 lanes/hop 20 util 0.94 pass-util 0.62 last-pass lanes/hop 32 LDS 45104 B conflicts rd x1.87 wr x1.64
-//     512: plan [4, 4, 4, 2] waves 4 lanes/hop 32 util 1.00 pass-util 1.00 last-pass lanes/hop 64 LDS 36832 B conflicts rd x2.00 wr x1.50
-//     640: plan [4, 4, 2, 5] waves 8 lanes/hop 40 util 0.94 pass-util 0.94 last-pass lanes/hop 64 LDS 67280 B conflicts rd x1.76 wr x1.33
+//     480: plan [8, 3, 5] waves 4 lanes/hop 20 util 0.94 pass-util 0.62 last-pass lanes/hop 32 LDS 45104 B conflicts rd x1.59 wr x1.58
+//     512: plan [8, 4, 4] waves 4 lanes/hop 32 util 1.00 pass-util 1.00 last-pass lanes/hop 64 LDS 38848 B conflicts rd x1.67 wr x1.33
+//     640: plan [8, 4, 5] waves 8 lanes/hop 40 util 0.94 pass-util 0.94 last-pass lanes/hop 64 LDS 67376 B conflicts rd x1.57 wr x1.44
 //     768: plan [4, 4, 4, 3] waves 3 (R = 1, GH = 3; measured +11 % over the 12-wave shape R = 4) lanes/hop 64 util 1.00 LDS 22224 B conflicts rd x2.25 wr x1.50
 //     800: plan [4, 2, 5, 5] waves 10 lanes/hop 40 util 0.94 pass-util 0.75 last-pass lanes/hop 32 LDS 80688 B conflicts rd x1.76 wr x1.66
 //     960: plan [4, 4, 3, 5] waves 4 lanes/hop 40 util 0.94 pass-util 0.62 last-pass lanes/hop 64 LDS 46896 B conflicts rd x1.83 wr x1.69
 //    1280: plan [4, 4, 4, 5] waves 5 lanes/hop 64 util 1.00 pass-util 1.00 last-pass lanes/hop 64 LDS 57520 B conflicts rd x2.25 wr x1.50
-//    2048: plan [4, 4, 4, 4, 2] waves 8 lanes/hop 128 util 1.00 pass-util 1.00 last-pass lanes/hop 64 LDS 77792 B conflicts rd x2.20 wr x1.40
+//    2048: plan [8, 8, 8] waves 8 lanes/hop 128 util 1.00 pass-util 1.00 last-pass lanes/hop 64 LDS 74624 B conflicts rd x2.00 wr x1.33
 //    4096: plan [4, 4, 4, 4, 4] waves 16 lanes/hop 512 util 1.00 pass-util 1.00 last-pass lanes/hop 64 LDS 81920 B conflicts rd x3.20 wr x1.60
 #define WH_MID_CONFIGS(X) \
     WH_MID_X(X, 320, WH_MID_320) \
-    X(1024, 1, 4, 0, 3, 16, 2, 0, 36, 0) \
-    X(64, 16, 4, 0, 3, 16, 1, 0, 36, 0) \
-    X(80, 12, 4, 0, 3, 20, 1, 1, 36, 0) \
-    X(96, 10, 4, 0, 3, 24, 1, 2, 36, 0) \
-    X(128, 8, 4, 0, 3, 32, 1, 2, 36, 0) \
-    X(160, 6, 4, 0, 3, 40, 1, 1, 36, 0) \
-    X(192, 5, 4, 0, 3, 48, 2, 4, 36, 0) \
-    X(240, 4, 4, 0, 3, 60, 1, 3, 36, 10) \
-    X(256, 4, 4, 0, 3, 16, 2, 0, 36, 0) \
-    X(384, 5, 4, 0, 2, 96, 1, 4, 36, 0) \
-    X(400, 3, 4, 0, 2, 100, 1, 0, 36, 20) \
-    X(480, 2, 4, 0, 3, 5, 2, 4, 36, 20) \
-    X(512, 2, 4, 0, 3, 32, 2, 0, 36, 0) \
-    X(640, 3, 4, 0, 2, 40, 2, 3, 36, 0) \
-    X(768, 1, 3, 0, 3, 48, 2, 0, 36, 0) \
-    X(800, 3, 4, 0, 2, 200, 2, 0, 36, 40) \
-    X(960, 1, 4, 0, 3, 5, 2, 4, 36, 40) \
-    X(1280, 1, 5, 0, 2, 80, 2, 0, 36, 0) \
-    X(2048, 1, 4, 0, 2, 32, 2, 0, 36, 0) \
-    X(4096, 1, 2, 0, 2, 1024, 1, 0, 36, 0)
+    X(1024, 1, 4, 0, 3, 32, 2, 0, 36, 0, 1) \
+    X(64, 16, 4, 0, 3, 16, 1, 0, 36, 0, 0) \
+    X(80, 12, 4, 0, 3, 20, 1, 1, 36, 0, 0) \
+    X(96, 10, 4, 0, 3, 24, 1, 2, 36, 0, 0) \
+    X(128, 8, 4, 0, 3, 32, 1, 2, 36, 0, 0) \
+    X(160, 6, 4, 0, 3, 40, 1, 1, 36, 0, 0) \
+    X(192, 5, 4, 0, 3, 48, 2, 4, 36, 0, 0) \
+    X(240, 4, 4, 0, 3, 60, 1, 3, 36, 10, 0) \
+    X(256, 4, 4, 0, 3, 16, 2, 0, 36, 0, 0) \
+    X(384, 5, 4, 0, 2, 96, 2, 4, 36, 0, 1) \
+    X(400, 3, 4, 0, 2, 100, 1, 0, 36, 20, 0) \
+    X(480, 2, 4, 0, 3, 5, 2, 4, 36, 20, 1) \
+    X(512, 2, 4, 0, 3, 16, 2, 0, 36, 0, 1) \
+    X(640, 3, 4, 0, 2, 20, 1, 4, 36, 0, 1) \
+    X(768, 1, 3, 0, 3, 48, 2, 0, 36, 0, 0) \
+    X(800, 3, 4, 0, 2, 200, 2, 0, 36, 40, 0) \
+    X(960, 1, 4, 0, 3, 5, 2, 4, 36, 40, 0) \
+    X(1280, 1, 5, 0, 2, 80, 2, 0, 36, 0, 0) \
+    X(2048, 1, 4, 0, 2, 64, 1, 0, 36, 0, 1) \
+    X(4096, 1, 2, 0, 2, 1024, 1, 0, 36, 0, 0)
 
 template <class C>
 int mid_launch_t(const PfbMidCall &c, hipStream_t st, long long *grid_out) {
@@ -908,6 +946,141 @@ int mid_launch_t(const PfbMidCall &c, hipStream_t st, long long *grid_out) {
     return WH_OK;
 }
 
+// ---- spectrum frames through the same passes (reference dsp/fft/scipy_backend.py:38-79: window -> FFT -> fftshift ->
+// 20 log10(|X| + 1e-10)).  A frame is an image: thread (r, u) windows the quad u, u + N/4, u + N/2, u + 3N/4 of GH frames,
+// does the radix-4 stage in registers and writes the images; the last pass turns its outputs into dB and stores them at
+// the fftshift-ed bin.  12 bytes of HBM traffic per sample (8 in, 4 out); the next round's samples are in flight during
+// the passes.
+struct SpecArgs {
+    const v2f *x;
+    size_t frame_stride;    // samples between frame starts
+    float *out;             // [n_frames][N]
+    float *sink;            // [N] nobody reads (frames past the end of the call)
+    const float *window;    // [N]
+    const float2 *tw;       // exp(-2 pi i m / N)
+    long long n_frames;
+};
+
+template <class C>
+__device__ __forceinline__ void spec_load(const SpecArgs &a, v2f (&cur)[C::GH][4], long long f0, int u) {
+#pragma unroll
+    for (int i = 0; i < C::GH; ++i) {
+        long long f = f0 + i;
+        if (f >= a.n_frames) f = a.n_frames - 1;
+        const v2f *px = a.x + (size_t)f * a.frame_stride + u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cur[i][q] = px[q * C::Q];
+    }
+}
+
+// last pass, spectrum form: bin f = kb + k BPL of the transform lands at (f + N/2) mod N = kb + ((k + RL/2) mod RL) BPL
+template <class C>
+__device__ __forceinline__ void mid_last_units_db(const v2f *img, float *out, float *sink, int lane, int wave,
+                                                  long long f0, long long limit) {
+    constexpr int r = C::RL, BPL = C::BPL, LSU = C::LSU, HR = 64 / LSU, KC = BPL / LSU;
+    constexpr int NU = (C::NIMG / HR) * KC, UPW = NU / C::NW;
+    static_assert(r % 2 == 0, "fftshift by a whole number of last-pass strides");
+    const int hs = HR == 1 ? 0 : lane / LSU, kl = lane - hs * LSU;
+    const v2f *base = img + hs * C::IMGS + C::ph(C::pos_of(kl));
+#pragma unroll
+    for (int i = 0; i < UPW; ++i) {
+        const int ui = wave * UPW + i;               // wave-uniform
+        const int hg = ui / KC, c = ui - hg * KC;
+        const long long frame = f0 + hg * HR + hs;
+        float *orow = (frame < limit ? out + (size_t)frame * C::M : sink) + kl + LSU * c;
+        const v2f *q = base + hg * HR * C::IMGS + C::ph(C::pos_of(LSU * c));
+        v2f v[r];
+#pragma unroll
+        for (int j = 0; j < r; ++j) v[j] = q[j];
+        bfly(v);
+#pragma unroll
+        for (int k = 0; k < r; ++k) {
+            // |X| + 1e-10 >= 1e-10 is a normal float: v_sqrt_f32 / v_log_f32 (1 ulp each; 20 log10 m = 20 log10(2) log2 m)
+            const float mag = __builtin_amdgcn_sqrtf(v[k].x * v[k].x + v[k].y * v[k].y) + 1e-10f;
+            orow[((k + r / 2) % r) * BPL] = 6.02059991327962390427f * __builtin_amdgcn_logf(mag);
+        }
+    }
+}
+
+template <class C>
+__global__ __launch_bounds__(C::NTL) void spectrum_mid_kernel(SpecArgs a) {
+    constexpr int M = C::M, GH = C::GH, Q = C::Q, NT = C::NTL, NIMG = C::NIMG, IMGS = C::IMGS;
+    constexpr MidPlan P = C::P;
+    static_assert(!C::WAVE_MODE && C::LSU > 0 && C::NT == C::NTL, "spectrum: workgroup-mode shapes with whole waves");
+    __shared__ __attribute__((aligned(16))) v2f img[NIMG * IMGS];
+    __shared__ v4f twp[P.twn > 0 ? P.twn : 1];
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int p = 0; p < P.np - 1; ++p) {
+        const int rp = P.r[p], Lp = P.L[p], mp = Lp / rp;
+        for (int e = tid; e < (rp - 1) * mp; e += NT) {
+            const int k = e / mp + 1, up = e - (k - 1) * mp;
+            const float2 w = a.tw[(up * k * (M / Lp)) % M];
+            twp[P.two[p] + e] = v4f{w.x, w.y, -w.y, w.x};
+        }
+    }
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = tid / Q, u = tid - r * Q;
+    v2f tw1, tw2, tw3;
+    {
+        const float2 w1 = a.tw[u], w2 = a.tw[2 * u], w3 = a.tw[3 * u];
+        tw1 = v2f{w1.x, w1.y}; tw2 = v2f{w2.x, w2.y}; tw3 = v2f{w3.x, w3.y};
+    }
+    float win[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) win[q] = a.window[u + q * Q];
+    const long long ngroups = (a.n_frames + NIMG - 1) / NIMG;
+    long long fg = blockIdx.x;
+    v2f cur[GH][4];
+    spec_load<C>(a, cur, fg * NIMG + r * GH, u);
+    v2f *const imr = img + r * GH * IMGS + C::ph(u);
+    __syncthreads();   // twiddle tables
+    for (; fg < ngroups; fg += gridDim.x) {
+#pragma unroll
+        for (int i = 0; i < GH; ++i) {
+            v2f y[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) y[q] = cur[i][q] * bc(win[q]);
+            bfly(y);
+            v2f *L = imr + i * IMGS;
+            L[0] = y[0];
+            L[C::ph(Q)] = cmul3(y[1], tw1);
+            L[C::ph(2 * Q)] = cmul3(y[2], tw2);
+            L[C::ph(3 * Q)] = cmul3(y[3], tw3);
+        }
+        const long long nxt = fg + gridDim.x;
+        if (nxt < ngroups) spec_load<C>(a, cur, nxt * NIMG + r * GH, u);
+        __syncthreads();
+        int lt = tid;
+        asm volatile("" : "+v"(lt));
+        mid_passes_affine<C, 0, C::TH, C::NIMG, true>(img, twp, lt);
+        mid_last_units_db<C>(img, a.out, a.sink, lt & 63, wave, fg * NIMG, a.n_frames);
+        __syncthreads();
+    }
+}
+
+template <class C>
+int spectrum_launch_t(const wh::SpectrumMidCall &c, hipStream_t st) {
+    static int wg_per_cu = 0;
+    auto kern = spectrum_mid_kernel<C>;
+    if (wg_per_cu == 0) {
+        int nb = 0;
+        WH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), C::NTL, 0));
+        wg_per_cu = nb > 0 ? nb : 1;
+    }
+    SpecArgs a;
+    a.x = reinterpret_cast<const v2f *>(c.x); a.frame_stride = c.frame_stride; a.out = c.out; a.sink = c.sink;
+    a.window = c.window; a.tw = c.tw; a.n_frames = c.n_frames;
+    const long long ngroups = (c.n_frames + C::NIMG - 1) / C::NIMG;
+    const long long slots = (long long)c.cu_count * wg_per_cu;
+    // whole rounds: every workgroup walks the same number of frame groups (a partial last round costs a full one)
+    const long long rounds = (ngroups + slots - 1) / slots;
+    const long long grid = (ngroups + rounds - 1) / rounds;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::NTL), 0, st, a);
+    WH_LAUNCH_CHECK();
+    return WH_OK;
+}
+
 }  // namespace
 
 #ifdef WH_DIAG
@@ -935,7 +1108,7 @@ bool pfb_mid_supported(int M, int T) {
     WH_MID_CONFIGS_T(X)
 #undef X
     if (T != 9) return false;
-#define X(M_, R_, GH_, NWF_, WPE_, PB_, PADN_, IMGX_, TREG_, LSP_) if (M == M_) return true;
+#define X(M_, R_, GH_, NWF_, WPE_, PB_, PADN_, IMGX_, TREG_, LSP_, R8_) if (M == M_) return true;
     WH_MID_CONFIGS(X)
 #undef X
     return false;
@@ -943,8 +1116,8 @@ bool pfb_mid_supported(int M, int T) {
 
 int pfb_mid_launch(int M, int T, const PfbMidCall &c, hipStream_t st, long long *grid_out) {
     if (T == 9) {
-#define X(M_, R_, GH_, NWF_, WPE_, PB_, PADN_, IMGX_, TREG_, LSP_) \
-    if (M == M_) return mid_launch_t<MidCfg<M_, 9, R_, GH_, NWF_, WPE_, PB_, PADN_, IMGX_, TREG_, LSP_>>(c, st, grid_out);
+#define X(M_, R_, GH_, NWF_, WPE_, PB_, PADN_, IMGX_, TREG_, LSP_, R8_) \
+    if (M == M_) return mid_launch_t<MidCfg<M_, 9, R_, GH_, NWF_, WPE_, PB_, PADN_, IMGX_, TREG_, LSP_, R8_>>(c, st, grid_out);
         WH_MID_CONFIGS(X)
 #undef X
     }
@@ -953,6 +1126,30 @@ int pfb_mid_launch(int M, int T, const PfbMidCall &c, hipStream_t st, long long 
     WH_MID_CONFIGS_T(X)
 #undef X
     return set_err(WH_E_ARG, "pfb_mid_launch: no instance for M=%d T=%d", M, T);
+}
+
+// spectrum frame sizes with a shaped kernel (layouts as the filterbank's at the same size; T = 1: no arms)
+//        N    R GH NWF WPE PB PADN IMGX TREG LSP R8
+#define WH_SPEC_CONFIGS(X) \
+    X(256, 4, 4, 0, 3, 8, 1, 0, 0, 0, 1) \
+    X(512, 2, 4, 0, 3, 16, 2, 0, 0, 0, 1) \
+    X(1024, 1, 4, 0, 3, 32, 2, 0, 0, 0, 1) \
+    X(2048, 1, 4, 0, 2, 64, 1, 0, 0, 0, 1) \
+    X(4096, 1, 2, 0, 2, 1024, 1, 0, 0, 0, 1)
+
+bool spectrum_mid_supported(int N) {
+#define X(N_, R_, GH_, NWF_, WPE_, PB_, PADN_, IMGX_, TREG_, LSP_, R8_) if (N == N_) return true;
+    WH_SPEC_CONFIGS(X)
+#undef X
+    return false;
+}
+
+int spectrum_mid_launch(int N, const SpectrumMidCall &c, hipStream_t st) {
+#define X(N_, R_, GH_, NWF_, WPE_, PB_, PADN_, IMGX_, TREG_, LSP_, R8_) \
+    if (N == N_) return spectrum_launch_t<MidCfg<N_, 1, R_, GH_, NWF_, WPE_, PB_, PADN_, IMGX_, TREG_, LSP_, R8_>>(c, st);
+    WH_SPEC_CONFIGS(X)
+#undef X
+    return set_err(WH_E_ARG, "spectrum_mid_launch: no instance for N=%d", N);
 }
 
 const char *pfb_mid_kernel_name() { return "pfb_mid_kernel"; }

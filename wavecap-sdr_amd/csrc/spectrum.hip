@@ -1,6 +1,9 @@
 // Spectrum frames (reference dsp/fft/scipy_backend.py:38-79): Hann window -> FFT -> fftshift ->
 // 20 log10(|X| + 1e-10), fused in one kernel, one workgroup per frame (batched over frames).
-// FFT: LDS Stockham radix-2 for power-of-two sizes, direct DFT otherwise.
+// FFT: frame sizes 256 .. 4096 go through the compile-time-shaped passes of pfb_mid.hip (spectrum_mid_kernel: in-place
+// DIF FFT in padded LDS images, several frames per workgroup, next frames prefetched); other power-of-two sizes take the
+// LDS Stockham kernel below (radix-4 passes), anything else the direct DFT.
+#include "pfb_internal.h"
 #include "wh_common.h"
 #include <cmath>
 #include <memory>
@@ -117,7 +120,11 @@ struct wh_spectrum {
     int N, log2N;
     float *d_window = nullptr;
     float2 *d_tw = nullptr;
+    float *d_sink = nullptr;   // [N] row for the shaped kernel's stores of frames past the end of a call
     size_t smem = 0;
+    bool shaped = false;       // a shaped instance exists for N
+    int path = 0;              // wh_spectrum_tune: 0 auto, 1 Stockham / DFT kernel, 2 shaped kernel
+    int cu_count = 256;
 };
 
 extern "C" int wh_spectrum_create(wh_spectrum **out, int N) {
@@ -140,6 +147,15 @@ extern "C" int wh_spectrum_create(wh_spectrum **out, int N) {
     WH_HIP(hipMalloc(&s->d_tw, (size_t)N * sizeof(float2)));
     WH_HIP(hipMemcpy(s->d_window, w.data(), (size_t)N * sizeof(float), hipMemcpyHostToDevice));
     WH_HIP(hipMemcpy(s->d_tw, tw.data(), (size_t)N * sizeof(float2), hipMemcpyHostToDevice));
+    WH_HIP(hipMalloc(&s->d_sink, (size_t)N * sizeof(float)));
+    s->shaped = spectrum_mid_supported(N);
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        WH_HIP(hipGetDevice(&dev));
+        WH_HIP(hipGetDeviceProperties(&prop, dev));
+        s->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
     s->smem = (size_t)N * sizeof(float2) * (s->log2N ? 2 : 1);
     if (s->smem > 64 * 1024)
         WH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(spectrum_kernel),
@@ -152,6 +168,7 @@ extern "C" void wh_spectrum_destroy(wh_spectrum *s) {
     if (!s) return;
     (void)hipFree(s->d_window);
     (void)hipFree(s->d_tw);
+    (void)hipFree(s->d_sink);
     delete s;
 }
 
@@ -161,10 +178,24 @@ extern "C" int wh_spectrum_run(wh_spectrum *s, const float *d_iq, size_t n_frame
     if (n_frames == 0) return WH_OK;
     if (!d_iq || !d_power_db) return set_err(WH_E_ARG, "wh_spectrum_run: null buffer");
     if (n_frames > 0x7fffffff) return set_err(WH_E_ARG, "wh_spectrum_run: too many frames");
+    if (s->shaped && s->path != 1) {
+        SpectrumMidCall c;
+        c.x = reinterpret_cast<const float2 *>(d_iq); c.frame_stride = frame_stride; c.n_frames = (long long)n_frames;
+        c.out = d_power_db; c.sink = s->d_sink; c.window = s->d_window; c.tw = s->d_tw; c.cu_count = s->cu_count;
+        return spectrum_mid_launch(s->N, c, as_stream(stream));
+    }
     hipLaunchKernelGGL(spectrum_kernel, dim3((unsigned)n_frames), dim3(256), s->smem, as_stream(stream),
                        reinterpret_cast<const float2 *>(d_iq), frame_stride, d_power_db, s->d_window, s->d_tw, s->N,
                        s->log2N);
     WH_LAUNCH_CHECK();
+    return WH_OK;
+}
+
+extern "C" int wh_spectrum_tune(wh_spectrum *s, int key, int value) {
+    if (!s) return set_err(WH_E_ARG, "wh_spectrum_tune: null handle");
+    if (key != 1 || value < 0 || value > 2) return set_err(WH_E_ARG, "wh_spectrum_tune: key 1 (kernel), value 0 auto / 1 stockham / 2 shaped");
+    if (value == 2 && !s->shaped) return set_err(WH_E_ARG, "wh_spectrum_tune: no shaped kernel for fft_size=%d", s->N);
+    s->path = value;
     return WH_OK;
 }
 

@@ -127,6 +127,7 @@ PROTOTYPES = {
     "wh_pfb_destroy": (None, [c_void_p]),
     "wh_spectrum_create": (c_int, [C.POINTER(c_void_p), c_int]),
     "wh_spectrum_run": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p]),
+    "wh_spectrum_tune": (c_int, [c_void_p, c_int, c_int]),
     "wh_spectrum_window": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p]),
     "wh_spectrum_post": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "wh_spectrum_destroy": (None, [c_void_p]),

@@ -68,11 +68,13 @@ class HipFFTBackend(FFTBackend):
     """MI355X spectrum backend (window + FFT + |.| + fftshift + log10 fused in one HIP kernel)."""
 
     def __init__(self, fft_size: int = 2048, engine: str = "fused"):
-        """engine "fused": one HIP kernel per frame (window, LDS FFT, |.|, shift, log).
+        """engine "fused": one HIP kernel (window, LDS FFT, |.|, shift, log); the library picks the shaped kernel for
+        fft_size 256 .. 4096, the Stockham / direct-DFT kernel otherwise.  "stockham" / "shaped" force one of the two
+        (tests, measurements).
         engine "rocfft": HIP window kernel -> rocFFT batched C2C (reached through torch.fft, which is
         hipFFT/rocFFT on ROCm) -> HIP epilogue kernel; the form BASELINE.json's north_star names."""
-        if engine not in ("fused", "rocfft"):
-            raise ValueError("engine must be 'fused' or 'rocfft'")
+        if engine not in ("fused", "rocfft", "stockham", "shaped"):
+            raise ValueError("engine must be 'fused', 'stockham', 'shaped' or 'rocfft'")
         self.engine = engine
         try:
             from . import _lib
@@ -86,6 +88,8 @@ class HipFFTBackend(FFTBackend):
         self._h = C.c_void_p()
         self._destroy = _lib.lib.wh_spectrum_destroy
         _lib.check(_lib.lib.wh_spectrum_create(C.byref(self._h), int(fft_size)), "wh_spectrum_create")
+        if engine in ("stockham", "shaped"):
+            _lib.check(_lib.lib.wh_spectrum_tune(self._h, 1, 1 if engine == "stockham" else 2), "wh_spectrum_tune")
         self._freq_cache: dict[int, np.ndarray] = {}
 
     def __del__(self):
