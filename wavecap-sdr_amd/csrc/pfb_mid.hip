@@ -828,9 +828,9 @@ int g_diag_stamp_wg = 0;
 #define WH_MID_X(X, ...) X(__VA_ARGS__)
 // Shapes found by tools/pfb_mid_configs.py (lane utilisation, LDS footprint, simulated bank conflicts).  Last column R8:
 // radix-8 passes for the power-of-two part (tools/pfb_mid_configs.py --r8) where fewer LDS passes measured faster
-// (2^26 samples: M = 2048 552 -> 446 us, 640 431 -> 399, 480 438 -> 409, 384 417 -> 406, 512 367 -> 356; no gain for
+// (2^26 samples: M = 2048 552 -> 446 us, 4096 697 -> 553, 640 431 -> 399, 480 438 -> 409, 384 417 -> 406, 512 367 -> 356; no gain for
 // M <= 256, which run at the memory system's pace already; 768 / 800 / 1280 have no affine radix-8 shape at these
-// workgroup sizes, 4096 spills at its 128-register budget):
+// workgroup sizes; 4096: 697 -> 553 us with 20 of its taps in registers, 3 spilled dwords in the complex64 form):
 //      64: plan [4, 4] waves 4 lanes/hop 4 util 1.00 pass-util 1.00 last-pass lanes/hop 16 LDS 35008 B conflicts rd x1.50 wr x1.00
 //      80: plan [4, 5] waves 4 lanes/hop 5 util 0.94 pass-util 0.94 last-pass lanes/hop 16 LDS 32880 B conflicts rd x2.90 wr x1.00
 //      96: plan [4, 2, 3] waves 4 lanes/hop 6 util 0.94 pass-util 0.94 last-pass lanes/hop 32 LDS 32976 B conflicts rd x1.66 wr x1.31
@@ -849,7 +849,8 @@ int g_diag_stamp_wg = 0;
 //     960: plan [4, 4, 3, 5] waves 4 lanes/hop 40 util 0.94 pass-util 0.62 last-pass lanes/hop 64 LDS 46896 B conflicts rd x1.83 wr x1.69
 //    1280: plan [4, 4, 4, 5] waves 5 lanes/hop 64 util 1.00 pass-util 1.00 last-pass lanes/hop 64 LDS 57520 B conflicts rd x2.25 wr x1.50
 //    2048: plan [8, 8, 8] waves 8 lanes/hop 128 util 1.00 pass-util 1.00 last-pass lanes/hop 64 LDS 74624 B conflicts rd x2.00 wr x1.33
-//    4096: plan [4, 4, 4, 4, 4] waves 16 lanes/hop 512 util 1.00 pass-util 1.00 last-pass lanes/hop 64 LDS 81920 B conflicts rd x3.20 wr x1.60
+//    4096: plan [8, 8, 4, 4] waves 16 lanes/hop 512 util 1.00 pass-util 1.00 last-pass lanes/hop 64 LDS 147456 B (20 register taps: the
+//          1024-thread workgroup has 128 registers per lane; one workgroup per CU) conflicts rd x3.75 wr x1.75
 #define WH_MID_CONFIGS(X) \
     WH_MID_X(X, 320, WH_MID_320) \
     X(1024, 1, 4, 0, 3, 32, 2, 0, 36, 0, 1) \
@@ -871,7 +872,7 @@ int g_diag_stamp_wg = 0;
     X(960, 1, 4, 0, 3, 5, 2, 4, 36, 40, 0) \
     X(1280, 1, 5, 0, 2, 80, 2, 0, 36, 0, 0) \
     X(2048, 1, 4, 0, 2, 64, 1, 0, 36, 0, 1) \
-    X(4096, 1, 2, 0, 2, 1024, 1, 0, 36, 0, 0)
+    X(4096, 1, 2, 0, 2, 1024, 1, 0, 20, 0, 1)
 
 template <class C>
 int mid_launch_t(const PfbMidCall &c, hipStream_t st, long long *grid_out) {
