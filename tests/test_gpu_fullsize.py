@@ -52,7 +52,7 @@ def test_config3_pfb_full_size_2p28():
 def test_config3_int16_dma_prefetch_full_size_bit_equal():
     """The int16 default of the 1024-channel kernel prefetches through the LDS DMA and waits with a COUNTED vmcnt (the
     prefetch retires, the eight younger output stores stay in flight; MI355X_MICROARCH.md: loads, stores and LDS-DMA
-    count together, in issue order) into a double-buffered LDS target.  At 2^28 samples every workgroup walks 32 groups
+    count together, in issue order) into a double-buffered LDS target.  At 2^28 samples every workgroup walks 64 groups
     with stores in flight and the whole chip contending for HBM -- the steady state the small tests never reach -- and
     the whole 524 287 x 1024 output plus the carried history must equal the register-prefetch kernel on the unpacked
     copy bit for bit; a second call runs with a no-arithmetic streaming kernel co-resident on another HIP stream to

@@ -1101,8 +1101,9 @@ static int pfb_run_fmt(wh_pfb *p, const void *d_iq, int fmt, size_t n, float *d_
             a.tw1024 = p->d_tw;
             a.first_hop = 8;
             a.n_groups = n_groups;
-            // runs of 128 hops (halo 7 %), but at least ~8 workgroups per CU when the input allows
-            int gpw = 32;
+            // runs of 256 hops (halo 3 %; 128 hops measured 2.5-4 % slower at 2^28 samples), but at least ~8 workgroups
+            // per CU when the input allows
+            int gpw = 64;
             long long nwg = (n_groups + gpw - 1) / gpw;
             while (gpw > 2 && nwg < (long long)p->cu_count * 8) {
                 gpw >>= 1;

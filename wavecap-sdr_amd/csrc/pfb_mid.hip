@@ -828,8 +828,8 @@ int g_diag_stamp_wg = 0;
 #define WH_MID_X(X, ...) X(__VA_ARGS__)
 // Shapes found by tools/pfb_mid_configs.py (lane utilisation, LDS footprint, simulated bank conflicts).  Last column R8:
 // radix-8 passes for the power-of-two part (tools/pfb_mid_configs.py --r8) where fewer LDS passes measured faster
-// (2^26 samples: M = 2048 552 -> 446 us, 4096 697 -> 553, 640 431 -> 399, 480 438 -> 409, 384 417 -> 406, 512 367 -> 356; no gain for
-// M <= 256, which run at the memory system's pace already; 768 / 800 / 1280 have no affine radix-8 shape at these
+// (2^26 samples: M = 2048 552 -> 446 us, 4096 697 -> 553, 800 482 -> 454, 640 431 -> 399, 480 438 -> 409, 384 417 -> 406, 512 367 -> 356; no gain for
+// M <= 256, which run at the memory system's pace already; 768 / 1280 have no affine radix-8 shape at these
 // workgroup sizes; 4096: 697 -> 553 us with 20 of its taps in registers, 3 spilled dwords in the complex64 form):
 //      64: plan [4, 4] waves 4 lanes/hop 4 util 1.00 pass-util 1.00 last-pass lanes/hop 16 LDS 35008 B conflicts rd x1.50 wr x1.00
 //      80: plan [4, 5] waves 4 lanes/hop 5 util 0.94 pass-util 0.94 last-pass lanes/hop 16 LDS 32880 B conflicts rd x2.90 wr x1.00
@@ -845,7 +845,7 @@ int g_diag_stamp_wg = 0;
 //     512: plan [8, 4, 4] waves 4 lanes/hop 32 util 1.00 pass-util 1.00 last-pass lanes/hop 64 LDS 38848 B conflicts rd x1.67 wr x1.33
 //     640: plan [8, 4, 5] waves 8 lanes/hop 40 util 0.94 pass-util 0.94 last-pass lanes/hop 64 LDS 67376 B conflicts rd x1.57 wr x1.44
 //     768: plan [4, 4, 4, 3] waves 3 (R = 1, GH = 3; measured +11 % over the 12-wave shape R = 4) lanes/hop 64 util 1.00 LDS 22224 B conflicts rd x2.25 wr x1.50
-//     800: plan [4, 2, 5, 5] waves 10 lanes/hop 40 util 0.94 pass-util 0.75 last-pass lanes/hop 32 LDS 80688 B conflicts rd x1.76 wr x1.66
+//     800: plan [8, 5, 5] waves 4 (R = 1, GH = 8: 482 -> 454 us against the 10-wave shape R = 3) lanes/hop 20 util 0.78 pass-util 0.62 last-pass lanes/hop 32 LDS 54320 B conflicts rd x1.59 wr x1.54
 //     960: plan [4, 4, 3, 5] waves 4 lanes/hop 40 util 0.94 pass-util 0.62 last-pass lanes/hop 64 LDS 46896 B conflicts rd x1.83 wr x1.69
 //    1280: plan [4, 4, 4, 5] waves 5 lanes/hop 64 util 1.00 pass-util 1.00 last-pass lanes/hop 64 LDS 57520 B conflicts rd x2.25 wr x1.50
 //    2048: plan [8, 8, 8] waves 8 lanes/hop 128 util 1.00 pass-util 1.00 last-pass lanes/hop 64 LDS 74624 B conflicts rd x2.00 wr x1.33
@@ -868,7 +868,7 @@ int g_diag_stamp_wg = 0;
     X(512, 2, 4, 0, 3, 16, 2, 0, 36, 0, 1) \
     X(640, 3, 4, 0, 2, 20, 1, 4, 36, 0, 1) \
     X(768, 1, 3, 0, 3, 48, 2, 0, 36, 0, 0) \
-    X(800, 3, 4, 0, 2, 200, 2, 0, 36, 40, 0) \
+    X(800, 1, 8, 0, 2, 0, 0, 0, 36, 20, 1) \
     X(960, 1, 4, 0, 3, 5, 2, 4, 36, 40, 0) \
     X(1280, 1, 5, 0, 2, 80, 2, 0, 36, 0, 0) \
     X(2048, 1, 4, 0, 2, 64, 1, 0, 36, 0, 1) \
