@@ -216,7 +216,8 @@ def _secondary_small_rows(torch):
         be.execute_device(x, frames)
     torch.cuda.synchronize()
     el = (time.perf_counter() - t0) / 10
-    out["spectrum"] = {"workload": "spectrum_kernel, 16384 frames of 2048 complex64 per call (12 B per sample: 8 in, 4 out)",
+    out["spectrum"] = {"workload": "spectrum_mid_kernel (window, 2048-point FFT, |X| dB, fftshift), 16384 frames of complex64 per call "
+                                   "(12 B per sample: 8 in, 4 out)",
                        "gsps": round(frames * N / el / 1e9, 1), "algorithmic_GBps": round(12.0 * frames * N / el / 1e9, 1),
                        "frac_of_8TBps": round(12.0 * frames * N / el / 1e9 / HBM_PEAK_GBPS, 4)}
     del x
