@@ -307,6 +307,12 @@ int wh_sync_positions(const float *d_scores, size_t n, float threshold, int32_t 
                       int32_t *d_count, void *stream);
 int wh_nid_extract(const uint8_t *d_dibits, size_t n, const int32_t *d_starts, size_t n_starts, uint64_t *d_words,
                    void *stream);
+/* Status-symbol stripping, decoders/p25.py:2796-2862 P25Decoder._strip_status_symbols: a counter starting at
+ * initial_counter (21 for a TSDU at frame position 57) is incremented per dibit; the dibit on which it reaches 36 is a
+ * status symbol and is dropped (counter back to 0).  d_dibits uint8 [n_rows][in_stride] (n dibits per row) -> d_out uint8
+ * [n_rows][out_stride]; *n_out (host) = dibits kept per row (the same for every row; also returned when n_rows == 0). */
+int wh_strip_status(const uint8_t *d_dibits, size_t n, size_t in_stride, int n_rows, int initial_counter,
+                    uint8_t *d_out, size_t out_stride, size_t *n_out, void *stream);
 typedef struct wh_bch wh_bch;
 int wh_bch_create(wh_bch **out, const uint64_t *h_codewords);
 int wh_bch_decode(wh_bch *b, const uint64_t *d_words, size_t n, const int32_t *d_tracked_nac, int32_t *d_data,

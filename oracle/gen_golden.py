@@ -574,6 +574,25 @@ def gen_nid():
     save("nid", **out)
 
 
+def gen_status():
+    """N2: P25Decoder._strip_status_symbols (decoders/p25.py:2796-2862) on random dibit rows: lengths around the
+    36-dibit period, the TSDU length (101+), long rows; initial counters 0, 21 (TSDU), 35 (first dibit is a status
+    symbol), 36 / 40 (the counter never meets 36: nothing stripped), -3."""
+    from wavecapsdr.decoders.p25 import P25Decoder
+
+    dec = P25Decoder.__new__(P25Decoder)      # the method reads class state only
+    rng = np.random.default_rng(2796)
+    out, k = {}, 0
+    for n in (0, 1, 13, 14, 15, 35, 36, 37, 72, 101, 120, 360, 2001):
+        for c0 in (0, 21, 35, 36, 40, -3):
+            d = rng.integers(0, 4, size=n).astype(np.uint8)
+            r = dec._strip_status_symbols(d, initial_counter=c0)
+            out[f"c{k}_in"], out[f"c{k}_c0"], out[f"c{k}_out"] = d, np.array(c0), np.asarray(r, dtype=np.uint8)
+            k += 1
+    out["n_cases"] = np.array(k)
+    save("status", **out)
+
+
 def gen_chain4():
     """Config 4, chained: IQ -> C4FMDemodulator.demodulate (dsp/p25/c4fm.py:2528) -> P25P1MessageFramer.process_batch
     (decoders/p25_framer.py:471-617), fed in 100 ms calls as cli.py:700-716 / decoders/p25.py:1961 do: every BCH
@@ -790,7 +809,7 @@ def gen_lsm():
     save("lsm", **out)
 
 
-ALL = dict(cqpsk_parts=gen_cqpsk_parts, chain4=gen_chain4, blanker=gen_blanker, nid=gen_nid, classifier=gen_classifier, recorder=gen_recorder, nr=gen_nr, sam=gen_sam, rawdig=gen_rawdig, lsm=gen_lsm, framer=gen_framer, cqpsk=gen_cqpsk, trunk=gen_trunk, a1=gen_a1, a2=gen_a2, a3=gen_a3, a6=gen_a6, chain=gen_chain, a7=gen_a7, a8=gen_a8, c4fm=gen_c4fm)
+ALL = dict(status=gen_status, cqpsk_parts=gen_cqpsk_parts, chain4=gen_chain4, blanker=gen_blanker, nid=gen_nid, classifier=gen_classifier, recorder=gen_recorder, nr=gen_nr, sam=gen_sam, rawdig=gen_rawdig, lsm=gen_lsm, framer=gen_framer, cqpsk=gen_cqpsk, trunk=gen_trunk, a1=gen_a1, a2=gen_a2, a3=gen_a3, a6=gen_a6, chain=gen_chain, a7=gen_a7, a8=gen_a8, c4fm=gen_c4fm)
 
 if __name__ == "__main__":
     import logging

@@ -906,6 +906,22 @@ def bch_decode(word: int, tracked_nac: int = 0):
     return dat, e
 
 
+def strip_status_symbols(dibits: np.ndarray, initial_counter: int = 21) -> np.ndarray:
+    """decoders/p25.py:2796-2862 (_get_status_keep_indices + _strip_status_symbols): the counter loop itself."""
+    d = np.asarray(dibits)
+    keep = []
+    counter = initial_counter
+    for i in range(len(d)):
+        counter += 1
+        if counter == 36:      # status symbol every 36 dibits
+            counter = 0
+            continue
+        keep.append(i)
+    if len(d) == 0:
+        return np.array([], dtype=np.uint8)
+    return np.asarray(d[np.array(keep, dtype=np.int64)], dtype=np.uint8) if keep else np.array([], dtype=np.uint8)
+
+
 class NIDFrontEnd:
     """process_batch's NID part: sync positions (score > 60) restart a 33-dibit collection that begins AT the dibit
     completing the sync; status dibit 11 dropped; BCH; NAC tracker (3 entries, dominant after 3 observations)."""

@@ -719,6 +719,31 @@ def test_n2_bch_decoder(wh, golden):
     assert np.array_equal(d, idx.astype(np.int32)) and np.all(e == 11)
 
 
+def test_n2_status_symbol_stripping(wh, golden, O):
+    """wh_strip_status == P25Decoder._strip_status_symbols (decoders/p25.py:2796-2862) on the reference's own outputs
+    (78 cases: lengths around the 36-dibit period, initial counters incl. 35, >= 36 and negative), bit for bit; batched
+    rows with a row stride; a long row against the oracle."""
+    import torch
+
+    g = golden("status")
+    for k in range(int(g["n_cases"])):
+        r = wh.strip_status_symbols(g[f"c{k}_in"], int(g[f"c{k}_c0"]))
+        assert r.dtype == np.uint8 and np.array_equal(r, g[f"c{k}_out"]), k
+    assert wh.strip_status_symbols([], 21).size == 0
+    rng = np.random.default_rng(2862)
+    rows = rng.integers(0, 4, size=(7, 5000)).astype(np.uint8)
+    wide = torch.from_numpy(np.concatenate([rows, rows[:, :13]], axis=1)).cuda()[:, :5000]      # row stride 5013
+    for c0 in (21, 0, 35, 50):
+        out = wh.strip_status_symbols_device(wide, c0).cpu().numpy()
+        for c in range(7):
+            assert np.array_equal(out[c], O.strip_status_symbols(rows[c], c0)), (c0, c)
+    long = rng.integers(0, 4, size=1_000_003).astype(np.uint8)
+    got = wh.strip_status_symbols(long, 21)
+    keep = np.ones(long.size, dtype=bool)
+    keep[14::36] = False                                   # first status symbol at 35 - 21
+    assert np.array_equal(got, long[keep])
+
+
 def test_n2_nid_front_end(wh, golden):
     """P25NIDFrontEnd == the NID events of the reference framer's process_batch (same ragged calls), and the events
     do not depend on how the stream is cut into calls."""

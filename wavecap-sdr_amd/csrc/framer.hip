@@ -125,6 +125,18 @@ __global__ void nid_extract_kernel(const uint8_t *dibits, int n, const int32_t *
     words[k] = w >> 1;   // drop the 64th bit
 }
 
+// status-symbol stripping (decoders/p25.py:2796-2862 _strip_status_symbols): a counter starts at c0, is incremented per
+// dibit, and the dibit on which it reaches 36 is a status symbol (dropped, counter back to 0) -- i.e. the inputs
+// s0 + 36 k with s0 = 35 - c0 are dropped (none when c0 > 35: the counter never meets 36).  Closed form per OUTPUT j:
+// input j below s0, j + 1 + (j - s0) / 35 from there on.  One thread per output, rows batched over blockIdx.y.
+__global__ void strip_status_kernel(const uint8_t *in, size_t in_stride, long long s0, long long n_out, uint8_t *out,
+                                    size_t out_stride) {
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_out) return;
+    const long long i = (s0 < 0 || j < s0) ? j : j + 1 + (j - s0) / 35;
+    out[(size_t)blockIdx.y * out_stride + j] = in[(size_t)blockIdx.y * in_stride + i];
+}
+
 // BCH(63,16,23) bounded-distance decoding by exhaustive nearest-codeword search: d_min = 23, so at most one of the
 // 65536 codewords lies within 11 bit errors of a word -- exactly the words the reference's Berlekamp-Massey / Chien /
 // re-check chain (bch.py:575-638) corrects, with the same (data, error count).  One workgroup per word; pass 2
@@ -221,6 +233,23 @@ extern "C" int wh_nid_extract(const uint8_t *d_dibits, size_t n, const int32_t *
         return set_err(WH_E_ARG, "wh_nid_extract: bad arguments");
     hipLaunchKernelGGL(nid_extract_kernel, dim3((unsigned)((n_starts + 255) / 256)), dim3(256), 0, as_stream(stream),
                        d_dibits, (int)n, d_starts, (int)n_starts, d_words);
+    WH_LAUNCH_CHECK();
+    return WH_OK;
+}
+
+extern "C" int wh_strip_status(const uint8_t *d_dibits, size_t n, size_t in_stride, int n_rows, int initial_counter,
+                               uint8_t *d_out, size_t out_stride, size_t *n_out, void *stream) {
+    if (!n_out || n_rows < 0 || n > 0x7fffffff) return set_err(WH_E_ARG, "wh_strip_status: bad arguments");
+    // dropped inputs: s0 + 36 k < n (s0 = 35 - initial_counter; none when the counter starts above 35)
+    const long long s0 = initial_counter <= 35 ? 35LL - initial_counter : -1;
+    const long long dropped = (s0 >= 0 && (long long)n > s0) ? ((long long)n - 1 - s0) / 36 + 1 : 0;
+    const long long kept = (long long)n - dropped;
+    *n_out = (size_t)kept;
+    if (kept == 0 || n_rows == 0) return WH_OK;
+    if (!d_dibits || !d_out || in_stride < n || out_stride < (size_t)kept)
+        return set_err(WH_E_ARG, "wh_strip_status: null buffer or stride shorter than the row");
+    hipLaunchKernelGGL(strip_status_kernel, dim3((unsigned)((kept + 255) / 256), (unsigned)n_rows), dim3(256), 0,
+                       as_stream(stream), d_dibits, in_stride, s0, kept, d_out, out_stride);
     WH_LAUNCH_CHECK();
     return WH_OK;
 }

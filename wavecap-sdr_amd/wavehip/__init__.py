@@ -20,7 +20,8 @@ from .channel_ops import (ChannelBank, ChannelConfig, ChannelDispatcher, process
 from .capture_seam import process_channels_parallel  # noqa: F401
 from . import channel_split  # noqa: F401
 from .wire import pack_iq16, unpack_iq16, pack_pcm16, pack_f32  # noqa: F401
-from .framer import P25P1SoftSyncDetector, SoftSyncBank, P25NIDFrontEnd, NACTracker  # noqa: F401
+from .framer import (P25P1SoftSyncDetector, SoftSyncBank, P25NIDFrontEnd, NACTracker,  # noqa: F401
+                     strip_status_symbols, strip_status_symbols_device)
 from .fec import BCHDecoder, bch_decode  # noqa: F401
 from .c4fm import C4FMBank, C4FMDemodulator, c4fm_demod_simple  # noqa: F401
 from .cqpsk import (CQPSKBank, CQPSKDemodulator, GardnerBank, GardnerTED, CostasBank, CostasLoop,  # noqa: F401
@@ -33,5 +34,5 @@ from .trunking import (TrunkingDDC, TrunkingDDCBank, ScannerMeasure, decimation_
 __all__ = [
     "PolyphaseChannelizer", "ChannelCalculator", "HipFFTBackend", "FFTResult", "FFTBackend", "is_available",
     "register_with", "process_channels_parallel", "ChannelBank", "ChannelConfig", "ChannelDispatcher", "noise_blanker", "process_channel_dsp_stateless", "update_signal_metrics", "pack_iq16", "unpack_iq16",
-    "pack_pcm16", "pack_f32", "P25P1SoftSyncDetector", "SoftSyncBank", "P25NIDFrontEnd", "NACTracker", "BCHDecoder", "bch_decode", "C4FMBank", "C4FMDemodulator", "c4fm_demod_simple", "CQPSKBank", "CQPSKDemodulator", "GardnerBank", "GardnerTED", "CostasBank", "CostasLoop", "MuellerMullerBank", "MuellerMullerTED", "LSMBank", "LSMDemodulator", "ChannelClassifier", "ClassifiedChannel", "TrunkingDDC", "TrunkingDDCBank", "ScannerMeasure", "decimation_plan", "recorder_decimation_plan",
+    "pack_pcm16", "pack_f32", "P25P1SoftSyncDetector", "SoftSyncBank", "P25NIDFrontEnd", "NACTracker", "strip_status_symbols", "strip_status_symbols_device", "BCHDecoder", "bch_decode", "C4FMBank", "C4FMDemodulator", "c4fm_demod_simple", "CQPSKBank", "CQPSKDemodulator", "GardnerBank", "GardnerTED", "CostasBank", "CostasLoop", "MuellerMullerBank", "MuellerMullerTED", "LSMBank", "LSMDemodulator", "ChannelClassifier", "ClassifiedChannel", "TrunkingDDC", "TrunkingDDCBank", "ScannerMeasure", "decimation_plan", "recorder_decimation_plan",
 ]

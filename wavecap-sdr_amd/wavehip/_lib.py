@@ -83,6 +83,7 @@ PROTOTYPES = {
     "wh_sync_correlate": (c_int, [c_void_p, c_size_t, c_size_t, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wh_sync_positions": (c_int, [c_void_p, c_size_t, c_float, c_void_p, c_size_t, c_void_p, c_void_p]),
     "wh_nid_extract": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "wh_strip_status": (c_int, [c_void_p, c_size_t, c_size_t, c_int, c_int, c_void_p, c_size_t, C.POINTER(c_size_t), c_void_p]),
     "wh_bch_create": (c_int, [C.POINTER(c_void_p), c_void_p]),
     "wh_bch_decode": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wh_bch_destroy": (None, [c_void_p]),

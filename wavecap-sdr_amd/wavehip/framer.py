@@ -100,6 +100,35 @@ class NACTracker:
         return nac if self._count[nac] >= self.MIN_OBSERVATION_THRESHOLD else 0
 
 
+def strip_status_symbols_device(dibits_dev, initial_counter: int = 21):
+    """uint8 GPU tensor [n] or [C, n] -> the rows without their status symbols (uint8 GPU tensor [kept] / [C, kept])."""
+    import ctypes as C
+
+    torch = _lib.require_gpu()
+    assert dibits_dev.is_cuda and dibits_dev.dtype == torch.uint8 and dibits_dev.dim() in (1, 2)
+    x = dibits_dev if dibits_dev.dim() == 2 else dibits_dev[None, :]
+    assert x.shape[1] == 0 or x.stride(1) == 1
+    rows, n = x.shape
+    out = torch.empty((rows, n), dtype=torch.uint8, device=x.device)
+    kept = C.c_size_t(0)
+    _lib.check(_lib.lib.wh_strip_status(x.data_ptr() if n else None, n, x.stride(0) if rows > 1 else max(n, 1), rows,
+                                        int(initial_counter), out.data_ptr() if n else None, max(n, 1), C.byref(kept),
+                                        _lib.stream_ptr(torch)), "wh_strip_status")
+    out = out[:, :kept.value]
+    return out if dibits_dev.dim() == 2 else out[0]
+
+
+def strip_status_symbols(dibits, initial_counter: int = 21) -> np.ndarray:
+    """Drop-in for P25Decoder._strip_status_symbols (decoders/p25.py:2816-2862): raw dibits with a status symbol every 36
+    dibits of the frame -> the clean dibit stream (uint8).  `initial_counter` is the frame position of the first dibit
+    modulo 36 (21 for a TSDU starting at frame position 57)."""
+    d = np.ascontiguousarray(np.asarray(dibits), dtype=np.uint8)
+    if d.size == 0:
+        return np.array([], dtype=np.uint8)
+    torch = _lib.require_gpu()
+    return strip_status_symbols_device(torch.from_numpy(d).cuda(), initial_counter).cpu().numpy()
+
+
 class P25NIDFrontEnd:
     """Front half of P25P1MessageFramer.process_batch (p25_framer.py:471-617) on the device: soft sync scores ->
     positions above SYNC_DETECTION_THRESHOLD -> the 33 dibits collected from each position (a later sync within the
