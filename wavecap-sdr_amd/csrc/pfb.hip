@@ -62,6 +62,7 @@ struct PfbFastArgs {
     long long n_groups;     // total groups of GH hops
     int groups_per_wg;
     int n_wg;
+    long long max_block;    // last half-block (512 samples) fully inside the input: prefetches past it are clamped
 #ifdef WH_DIAG
     int ablate;             // diagnostics build only (WH_PFB_ABLATE): 1 = suppress stores
 #endif
@@ -126,8 +127,8 @@ __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
         wB[i] = ld_iq<FMT>(a.x, xp + i * FHOP + 256);
     }
 
-    if (GLDS) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the window fill is complete before the loop, so that no
-                                                    // wait for it is placed inside the loop (it would drain the stores)
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the window fill is complete before the loop, so that no wait for it is
+                                          // placed inside the loop (the static wait would drain the stores in every iteration)
     for (long long g = g0; g < g1; ++g, h += GH) {
         unsigned char *pre = pre0 + (((g - g0) & 1) ? PRE_BYTES : 0);   // buffer of the copy issued in this iteration
         // ---- arm MAC + radix-4 stage for GH hops --------------------------------------------
@@ -164,8 +165,8 @@ __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
             wA[i] = wA[i + GH];
             wB[i] = wB[i + GH];
         }
-        if (g + 1 < g1) {   // (a second prefetch stage, one more group ahead, measured 1 % slower)
-            if (GLDS) {
+        if (GLDS) {
+            if (g + 1 < g1) {   // (a second prefetch stage, one more group ahead, measured 1 % slower)
                 // GH half-blocks, contiguous in memory, copied linearly: 16 bytes per lane, lane-linear in LDS
                 constexpr int NJ = PRE_BYTES / 16 / 256;
                 const unsigned char *src = reinterpret_cast<const unsigned char *>(a.x) +
@@ -182,13 +183,19 @@ __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
                                  "s_mov_b32 m0, %0"
                                  : "=&s"(save) : "s"(base), "v"(gp) : "memory");
                 }
-            } else {
-                const long long xn = (h + GH + 1) * FHOP + t;
+            }
+        } else {
+            // register prefetch, UNCONDITIONAL (the last group of a run loads clamped blocks nobody uses): with the loads
+            // under `if (g + 1 < g1)` the two paths into the next iteration carry different numbers of operations in
+            // flight, and hipcc's merged wait for the prefetched registers ends in vmcnt(0) -- every group then drained its
+            // predecessor's output stores before its arm MAC; with one path the waits are counted (the 8 stores stay in
+            // flight)
 #pragma unroll
-                for (int i = 0; i < GH; ++i) {
-                    wA[9 + i] = ld_iq<FMT>(a.x, xn + i * FHOP);
-                    wB[9 + i] = ld_iq<FMT>(a.x, xn + i * FHOP + 256);
-                }
+            for (int i = 0; i < GH; ++i) {
+                long long blk = h + GH + 1 + i;
+                blk = blk > a.max_block ? a.max_block : blk;
+                wA[9 + i] = ld_iq<FMT>(a.x, blk * FHOP + t);
+                wB[9 + i] = ld_iq<FMT>(a.x, blk * FHOP + t + 256);
             }
         }
         __syncthreads();
@@ -1115,6 +1122,7 @@ static int pfb_run_fmt(wh_pfb *p, const void *d_iq, int fmt, size_t n, float *d_
             }
             a.groups_per_wg = gpw;
             a.n_wg = (int)nwg;
+            a.max_block = (long long)(n / (size_t)FHOP) - 1;
 #ifdef WH_DIAG
             a.ablate = p->ablate;
 #endif
