@@ -126,7 +126,7 @@ typedef struct wh_chanbank_cfg {
                                        samples (derived by the host from the pole radii); lets chains without AGC run
                                        time-parallel (64 segments per row, each warmed up over iir_warmup samples);
                                        0 = strictly sequential recurrences */
-    int iir_scan;                   /* 1: the chain may run as an exact linear-recurrence scan (64 segments per row; per
+    int iir_scan;                   /* 1: the chain may run as an exact linear-recurrence scan (64, 256 or 512 segments per row; per
                                        stage: zero-state pass, start states from s' = M s + e with M = transition^segment,
                                        output pass; the AGC envelopes likewise).  The host sets it only when every M is
                                        well conditioned: the reference's order-5 ba-form high-/band-passes are NOT (their

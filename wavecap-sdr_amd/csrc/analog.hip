@@ -733,13 +733,17 @@ __global__ void iir_pow_kernel(StageArr sa, int n_stages, AgcDev agc, int seg, S
     }
 }
 
+// Start states of a wave's 64 segments from their zero-state end states e_p (in z): s_0 = start, s_{p+1} = M s_p + e_p.
+// On return z holds the lane's start state and `start` the state after the wave's last segment (the next wave's start
+// when this wave started from `start`; with start = 0 the wave's own zero-state end state).
 template <int NC>
-__device__ __forceinline__ void scan_states(double (&z)[MAX_ORD - 1], const double (*M)[MAX_ORD - 1], int lane, bool f64) {
+__device__ __forceinline__ void scan_states(double (&z)[MAX_ORD - 1], const double (*M)[MAX_ORD - 1], int lane, bool f64,
+                                            double (&start)[MAX_ORD - 1]) {
     constexpr int m = NC - 1;
     double cur[m > 0 ? m : 1], mine[m > 0 ? m : 1];
 #pragma unroll
-    for (int k = 0; k < m; ++k) { cur[k] = 0.0; mine[k] = 0.0; }
-    for (int p = 0; p < 63; ++p) {
+    for (int k = 0; k < m; ++k) { cur[k] = start[k]; mine[k] = start[k]; }
+    for (int p = 0; p < 64; ++p) {
         double nxt[m > 0 ? m : 1];
 #pragma unroll
         for (int i = 0; i < m; ++i) {
@@ -755,51 +759,60 @@ __device__ __forceinline__ void scan_states(double (&z)[MAX_ORD - 1], const doub
         }
     }
 #pragma unroll
-    for (int k = 0; k < m; ++k) z[k] = mine[k];
+    for (int k = 0; k < m; ++k) { z[k] = mine[k]; start[k] = cur[k]; }
 }
 
 __device__ __forceinline__ void scan_stage_states(double (&z)[MAX_ORD - 1], const double (*M)[MAX_ORD - 1], int n, int lane,
-                                                  bool f64) {
+                                                  bool f64, double (&start)[MAX_ORD - 1]) {
     switch (n) {
-        case 2: scan_states<2>(z, M, lane, f64); break;
-        case 3: scan_states<3>(z, M, lane, f64); break;
-        case 4: scan_states<4>(z, M, lane, f64); break;
-        case 5: scan_states<5>(z, M, lane, f64); break;
-        case 6: scan_states<6>(z, M, lane, f64); break;
-        case 7: scan_states<7>(z, M, lane, f64); break;
-        case 8: scan_states<8>(z, M, lane, f64); break;
-        case 9: scan_states<9>(z, M, lane, f64); break;
-        case 10: scan_states<10>(z, M, lane, f64); break;
-        case 11: scan_states<11>(z, M, lane, f64); break;
+        case 2: scan_states<2>(z, M, lane, f64, start); break;
+        case 3: scan_states<3>(z, M, lane, f64, start); break;
+        case 4: scan_states<4>(z, M, lane, f64, start); break;
+        case 5: scan_states<5>(z, M, lane, f64, start); break;
+        case 6: scan_states<6>(z, M, lane, f64, start); break;
+        case 7: scan_states<7>(z, M, lane, f64, start); break;
+        case 8: scan_states<8>(z, M, lane, f64, start); break;
+        case 9: scan_states<9>(z, M, lane, f64, start); break;
+        case 10: scan_states<10>(z, M, lane, f64, start); break;
+        case 11: scan_states<11>(z, M, lane, f64, start); break;
         default: break;   // n == 1: no state
     }
 }
 
-// scalar affine scan for a one-pole: start_{p+1} = pw * start_p + e_p (float64, rounded to float32 each step)
-__device__ __forceinline__ float scan_scalar(float e, double pw, int lane) {
-    double cur = 0.0;
-    float mine = 0.0f;
-    for (int p = 0; p < 63; ++p) {
+// scalar affine scan for a one-pole: s_0 = start, s_{p+1} = pw * s_p + e_p (float64, rounded to float32 each step);
+// returns the lane's start value, `start` becomes the value after the wave's last segment
+__device__ __forceinline__ float scan_scalar(float e, double pw, int lane, double &start) {
+    double cur = start;
+    float mine = (float)start;
+    for (int p = 0; p < 64; ++p) {
         cur = (double)(float)fma(pw, cur, (double)__shfl(e, p));
         if (lane == p + 1) mine = (float)cur;
     }
+    start = cur;
     return mine;
 }
 
-__global__ __launch_bounds__(64) void chan_rows_scan_kernel(float *rows, double *acc, int N, StageArr sa, int n_stages,
-                                                           AgcDev agc, int seg, const ScanPow *pw) {
-    __shared__ float tile[ROWS_CH][65];
+// A row is cut into 64 W segments, W = blockDim.x / 64 waves (the host picks W from the bank's channel count and chunk
+// length only).  With W > 1 a scan runs twice: from zero (the wave's own end state E_w goes to LDS), then -- after the
+// wave's true start W_w = fold of E_0 .. E_{w-1} through the 64-segment transition (pw[1]) -- from W_w.
+__global__ __launch_bounds__(64 * ROWS_MAXW) void chan_rows_scan_kernel(float *rows, double *acc, int N, StageArr sa,
+                                                                       int n_stages, AgcDev agc, int seg, const ScanPow *pw) {
+    extern __shared__ __attribute__((aligned(16))) float tile_raw[];   // per wave [ROWS_CH][65]
     __shared__ StageDev st_s[MAX_STAGES];
-    __shared__ double M_s[MAX_ORD - 1][MAX_ORD - 1];
-    const int lane = threadIdx.x;
-    for (int i = lane; i < n_stages * (int)(sizeof(StageDev) / 4); i += 64)
+    __shared__ double M_s[2][MAX_ORD - 1][MAX_ORD - 1];   // segment transition, 64-segment transition
+    __shared__ double exch[ROWS_MAXW][MAX_ORD - 1];
+    __shared__ double red_s[ROWS_MAXW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = blockDim.x >> 6;
+    float (*tile)[65] = reinterpret_cast<float (*)[65]>(tile_raw + (size_t)wave * ROWS_CH * 65);
+    for (int i = threadIdx.x; i < n_stages * (int)(sizeof(StageDev) / 4); i += blockDim.x)
         reinterpret_cast<int *>(st_s)[i] = reinterpret_cast<const int *>(sa.st)[i];
     __syncthreads();
     float *row = rows + (size_t)blockIdx.x * N;
-    int nr = (N + seg - 1) / seg;
-    if (nr > 64) nr = 64;
+    const int s0 = wave * 64;                       // first segment of this wave
+    int nr = (N + seg - 1) / seg - s0;              // live segments of this wave
+    nr = nr < 0 ? 0 : (nr > 64 ? 64 : nr);
     auto vn = [&](int l) -> int {
-        const int left = N - l * seg;
+        const int left = N - (s0 + l) * seg;
         return left < seg ? (left > 0 ? left : 0) : seg;
     };
     const int my_n = lane < nr ? vn(lane) : 0;
@@ -811,7 +824,7 @@ __global__ __launch_bounds__(64) void chan_rows_scan_kernel(float *rows, double 
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
                     const int l = l0 + u;
-                    v[u] = (l < nr && lane < vn(l) - i0) ? row[(size_t)l * seg + i0 + lane] : 0.0f;
+                    v[u] = (l < nr && lane < vn(l) - i0) ? row[(size_t)(s0 + l) * seg + i0 + lane] : 0.0f;
                 }
 #pragma unroll
                 for (int u = 0; u < 16; ++u)
@@ -824,7 +837,7 @@ __global__ __launch_bounds__(64) void chan_rows_scan_kernel(float *rows, double 
             __syncthreads();
             if (write)
                 for (int l = 0; l < nr; ++l)
-                    if (lane < vn(l) - i0) row[(size_t)l * seg + i0 + lane] = tile[lane][l];
+                    if (lane < vn(l) - i0) row[(size_t)(s0 + l) * seg + i0 + lane] = tile[lane][l];
             __syncthreads();
         }
     };
@@ -832,7 +845,10 @@ __global__ __launch_bounds__(64) void chan_rows_scan_kernel(float *rows, double 
     for (int s = 0; s < n_stages; ++s) {
         const bool f64 = st_s[s].is_f64 != 0;
         const int n = __builtin_amdgcn_readfirstlane(st_s[s].n);
-        for (int i = lane; i < (MAX_ORD - 1) * (MAX_ORD - 1); i += 64) (&M_s[0][0])[i] = (&pw->m[s][0][0])[i];
+        for (int i = threadIdx.x; i < (MAX_ORD - 1) * (MAX_ORD - 1); i += blockDim.x) {
+            (&M_s[0][0][0])[i] = (&pw[0].m[s][0][0])[i];
+            (&M_s[1][0][0])[i] = (&pw[1].m[s][0][0])[i];
+        }
         double z[MAX_ORD - 1];
 #pragma unroll
         for (int k = 0; k < MAX_ORD - 1; ++k) z[k] = 0.0;
@@ -842,7 +858,34 @@ __global__ __launch_bounds__(64) void chan_rows_scan_kernel(float *rows, double 
         };
         stream(false, run);                       // 1. zero-state end states
         __syncthreads();
-        scan_stage_states(z, M_s, n, lane, f64);  // 2. true start states
+        double start[MAX_ORD - 1];
+#pragma unroll
+        for (int k = 0; k < MAX_ORD - 1; ++k) start[k] = 0.0;
+        if (W > 1) {                              // 2a. the wave's start state
+            double e[MAX_ORD - 1];
+#pragma unroll
+            for (int k = 0; k < MAX_ORD - 1; ++k) e[k] = z[k];
+            scan_stage_states(e, M_s[0], n, lane, f64, start);
+            if (lane == 0)
+#pragma unroll
+                for (int k = 0; k < MAX_ORD - 1; ++k) exch[wave][k] = start[k];
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < MAX_ORD - 1; ++k) start[k] = 0.0;
+            for (int w = 0; w < wave; ++w) {
+                double nxt[MAX_ORD - 1];
+#pragma unroll
+                for (int i = 0; i < MAX_ORD - 1; ++i) {
+                    double a2 = exch[w][i];
+#pragma unroll
+                    for (int j = 0; j < MAX_ORD - 1; ++j) a2 = fma(M_s[1][i][j], start[j], a2);
+                    nxt[i] = f64 ? a2 : (double)(float)a2;
+                }
+#pragma unroll
+                for (int i = 0; i < MAX_ORD - 1; ++i) start[i] = nxt[i];
+            }
+        }
+        scan_stage_states(z, M_s[0], n, lane, f64, start);   // 2. true start states
         const bool last = (s == n_stages - 1) && !agc.on;
         stream(true, [&](int cnt) {               // 3. the outputs
             run(cnt);
@@ -857,6 +900,19 @@ __global__ __launch_bounds__(64) void chan_rows_scan_kernel(float *rows, double 
     if (agc.on) {
         const float NORM = (float)(1.0 / 0.90514825364486640);
         float za = 0.f, zr = 0.f;
+        // scalar two-level scan: e = the lane's zero-state end value, pws / pww = one-pole transition over a segment / 64
+        auto scan2 = [&](float e, double pws, double pww) -> float {
+            double start = 0.0;
+            if (W > 1) {
+                (void)scan_scalar(e, pws, lane, start);
+                if (lane == 0) exch[wave][0] = start;
+                __syncthreads();
+                start = 0.0;
+                for (int w = 0; w < wave; ++w) start = (double)(float)fma(pww, start, exch[w][0]);
+                __syncthreads();
+            }
+            return scan_scalar(e, pws, lane, start);
+        };
         // attack envelope: zero-state end value, scan
         stream(false, [&](int cnt) {
             for (int j = 0; j < cnt; ++j) {
@@ -864,7 +920,7 @@ __global__ __launch_bounds__(64) void chan_rows_scan_kernel(float *rows, double 
                 za = __fsub_rn(0.0f, __fmul_rn(ya, agc.att_a1));
             }
         });
-        const float za0 = scan_scalar(za, pw->att, lane);
+        const float za0 = scan2(za, pw[0].att, pw[1].att);
         // release envelope fed by the true attack envelope: zero-state end value, scan
         za = za0;
         stream(false, [&](int cnt) {
@@ -876,7 +932,7 @@ __global__ __launch_bounds__(64) void chan_rows_scan_kernel(float *rows, double 
                 zr = __fsub_rn(__fmul_rn(ya, 0.0f), __fmul_rn(yr, agc.rel_a1));
             }
         });
-        const float zr0 = scan_scalar(zr, pw->rel, lane);
+        const float zr0 = scan2(zr, pw[0].rel, pw[1].rel);
         za = za0;
         zr = zr0;
         stream(true, [&](int cnt) {
@@ -898,7 +954,13 @@ __global__ __launch_bounds__(64) void chan_rows_scan_kernel(float *rows, double 
         });
     }
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
-    if (lane == 0) acc[(size_t)blockIdx.x * 2 + 1] = ss;
+    if (lane == 0) red_s[wave] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < W; ++w) t += red_s[w];
+        acc[(size_t)blockIdx.x * 2 + 1] = t;
+    }
 }
 
 // finalize.  post 0 (FM): scale by 0.18/rms (dsp/fm.py:42-62) + soft clip x0.95 (fm.py:26-39);
@@ -1267,7 +1329,7 @@ struct wh_chanbank {
     double *d_taps = nullptr;
     StageArr stages{};
     ScanPow *d_pow = nullptr;   // scan form: per-stage state-transition powers for the bank's segment length
-    int scan_seg = 0;
+    int scan_seg = 0, scan_w = 1;   // scan form: segment length, waves per row (64 segments each)
     double *d_acc = nullptr;
     float *d_fm = nullptr;
     size_t cap_chunks = 0;
@@ -1358,21 +1420,42 @@ extern "C" int wh_chanbank_create(wh_chanbank **out, const wh_chanbank_cfg *c) {
         }
         for (int i = 0; i < c->n_stages; ++i) b->stages.st[i] = sd[i];
     }
-    // exact scan form of the rows for long chunks that the warm-up form cannot take (see chan_rows_scan_kernel)
+    // exact scan form of the rows (see chan_rows_scan_kernel): for long chunks that the warm-up form cannot take, and
+    // wherever its sequential depth is the shorter one -- the warm-up form walks segment + warm-up samples per lane, the
+    // scan form twice the segment plus the state scans (about 40 sample-equivalents per stage and scan).  Waves per row:
+    // a property of the bank (channel count, chunk length), never of the call.
     if (c->iir_scan && (c->n_stages > 0 || c->agc) && c->chunk_len >= 4096) {
-        const int sg = (c->chunk_len + 63) / 64;
-        const bool warm_ok = !c->agc && c->iir_warmup > 0 && c->n_stages > 0 && sg + c->iir_warmup <= c->chunk_len / 2;
-        if (!warm_ok) {
+        int w = c->n_channels <= 16 ? ROWS_MAXW : c->n_channels <= 64 ? 4 : 1;
+        while (w > 1 && c->chunk_len < 64 * w * 16) w >>= 1;
+        const int sg = (c->chunk_len + 64 * w - 1) / (64 * w);
+        long long depth_warm = -1;
+        if (!c->agc && c->iir_warmup > 0 && c->n_stages > 0 && (c->chunk_len + 63) / 64 + c->iir_warmup <= c->chunk_len / 2) {
+            int rw = c->n_stages > 3 ? 1 : w;   // (the warm-up kernel's own wave count, see wh_chanbank_run)
+            depth_warm = (c->chunk_len + 64 * rw - 1) / (64 * rw) + c->iir_warmup;
+        }
+        const long long depth_scan = 2LL * sg + 40LL * (c->n_stages + (c->agc ? 2 : 0)) * (w > 1 ? 2 : 1);
+        if (depth_warm < 0 || depth_scan < depth_warm) {
             b->scan_seg = sg;
+            b->scan_w = w;
             AgcDev g;
             g.on = c->agc; g.target = c->agc_target; g.max_gain = c->agc_max_gain;
             g.att_b0 = c->agc_att_b0; g.att_a1 = c->agc_att_a1; g.rel_b0 = c->agc_rel_b0; g.rel_a1 = c->agc_rel_a1;
-            WH_HIP(hipMalloc(&b->d_pow, sizeof(ScanPow)));
-            WH_HIP(hipMemset(b->d_pow, 0, sizeof(ScanPow)));
+            // transition powers over one segment and over a wave's 64 segments
+            WH_HIP(hipMalloc(&b->d_pow, 2 * sizeof(ScanPow)));
+            WH_HIP(hipMemset(b->d_pow, 0, 2 * sizeof(ScanPow)));
             hipLaunchKernelGGL(iir_pow_kernel, dim3(c->n_stages + 1), dim3(MAX_ORD - 1), 0, nullptr, b->stages, c->n_stages, g,
                                sg, b->d_pow);
             WH_LAUNCH_CHECK();
+            if (w > 1) {
+                hipLaunchKernelGGL(iir_pow_kernel, dim3(c->n_stages + 1), dim3(MAX_ORD - 1), 0, nullptr, b->stages, c->n_stages,
+                                   g, 64 * sg, b->d_pow + 1);
+                WH_LAUNCH_CHECK();
+            }
             WH_HIP(hipDeviceSynchronize());
+            const size_t tile_bytes = (size_t)w * ROWS_CH * 65 * sizeof(float);
+            if (tile_bytes > 64 * 1024)
+                WH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chan_rows_scan_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_bytes));
         }
     }
     // fused path: plain FM (no IIR stage, no AGC), pure decimation, everything fits in LDS
@@ -1520,7 +1603,8 @@ extern "C" int wh_chanbank_run_wire(wh_chanbank *b, const void *d_in, size_t n_c
                 }
             }
             if (b->scan_seg) {
-                hipLaunchKernelGGL(chan_rows_scan_kernel, dim3((unsigned)rows), dim3(64), 0, st, a.fm_out, b->d_acc, c.chunk_len,
+                hipLaunchKernelGGL(chan_rows_scan_kernel, dim3((unsigned)rows), dim3(64 * b->scan_w),
+                                   (size_t)b->scan_w * ROWS_CH * 65 * sizeof(float), st, a.fm_out, b->d_acc, c.chunk_len,
                                    b->stages, c.n_stages, g, b->scan_seg, b->d_pow);
                 WH_LAUNCH_CHECK();
             } else {

@@ -307,7 +307,8 @@ class ChannelBank:
             raise ValueError("iir_form must be 'auto' or 'sequential'")
         par = iir_form == "auto"
         cfg.iir_warmup = iir_warmup_samples(stages) if (par and stages and agc is None and demod < 3) else 0
-        cfg.iir_scan = 1 if (par and iir_scan_safe(stages, (self.chunk_len + 63) // 64)) else 0
+        # (the library cuts a row into 64, 256 or 512 segments by channel count: safe for each of them)
+        cfg.iir_scan = 1 if (par and all(iir_scan_safe(stages, (self.chunk_len + 64 * w - 1) // (64 * w)) for w in (1, 4, 8))) else 0
         if stages:
             arr = (_lib.IirStage * len(stages))(*stages)
             cfg.h_stages = arr
