@@ -131,6 +131,10 @@ typedef struct wh_chanbank_cfg {
                                        output pass; the AGC envelopes likewise).  The host sets it only when every M is
                                        well conditioned: the reference's order-5 ba-form high-/band-passes are NOT (their
                                        DF2T states cancel over ~1e6), those chains stay sequential */
+    int iir_warmup_form;            /* time-parallel warm-up form: 0 = the segments' start states are the dot product of the
+                                       iir_warmup samples before the segment with the chain's impulse-response states
+                                       (produced at creation by the recurrences themselves); 1 = by running the recurrences
+                                       over those samples (the same truncation, 16x the arithmetic; kept for comparison) */
     const float *h_squelch_db;      /* optional float32[n_channels] (NaN = none): audio of a chunk whose rssi_db is below
                                        the channel's threshold is zeroed (capture.py:2918-2921); metrics unaffected */
 } wh_chanbank_cfg;

@@ -765,10 +765,11 @@ def test_n2_nid_front_end(wh, golden):
 
 
 def test_chain_wbfm_time_parallel_iir_equals_sequential(wh, golden):
-    """The time-parallel form of the IIR rows (64 segments per row, each warmed up over the samples before it; used
-    when the chain has no AGC and its impulse responses die out well inside the chunk) against the strictly
-    sequential recurrence (WH_IIR_SEQ=1): same audio to ~1e-7 of peak (float32 stage rounding noise), both within
-    the tolerance of the reference golden; and the warm-up length the host derives covers the slowest pole."""
+    """The time-parallel form of the IIR rows (64 segments per wave and row; a segment's start states are the dot product
+    of the warm-up samples before it with the chain's impulse-response states -- or, iir_form="warmup_recurrence", the
+    recurrences run over those samples; used when the chain has no AGC and its impulse responses die out well inside
+    the chunk) against the strictly sequential recurrence: same audio to ~1e-7 of peak (float32 stage rounding noise),
+    all within the tolerance of the reference golden; and the warm-up length the host derives covers the slowest pole."""
     from wavehip.channel_ops import build_chain, iir_warmup_samples
     g = golden("chain_analog")
     fs, n, seed, off = (int(v) for v in g["wbfm1_args"])
@@ -777,11 +778,20 @@ def test_chain_wbfm_time_parallel_iir_equals_sequential(wh, golden):
     stages = build_chain(cfg, fs)[2]
     warm = iir_warmup_samples(stages)
     assert 1898 < warm < 4000                       # butter(5, 15 kHz @ 2.4 MS/s): slowest pole radius 0.98794, 1e-10 after 1 898 samples
-    par = wh.ChannelBank(fs, n, [cfg]).process(iq)[0][0]
+    par = wh.ChannelBank(fs, n, [cfg]).process(iq)[0][0]             # start states from the chain's impulse response
+    rec = wh.ChannelBank(fs, n, [cfg], iir_form="warmup_recurrence").process(iq)[0][0]   # ... from the recurrences
     seq = wh.ChannelBank(fs, n, [cfg], iir_form="sequential").process(iq)[0][0]
     ref = g["wbfm1_audio"]
-    assert peak_rel_err(par, ref) <= TOL and peak_rel_err(seq, ref) <= TOL
-    assert peak_rel_err(par, seq) <= 1e-6
+    assert peak_rel_err(par, ref) <= TOL and peak_rel_err(seq, ref) <= TOL and peak_rel_err(rec, ref) <= TOL
+    assert peak_rel_err(par, seq) <= 1e-6 and peak_rel_err(rec, seq) <= 1e-6
+    print(f"wbfm rows: impulse-response start states vs sequential {peak_rel_err(par, seq):.2e}, "
+          f"warm-up recurrence vs sequential {peak_rel_err(rec, seq):.2e}")
+    # several channels per bank (4 waves per row) and a ragged chunk length
+    n2 = n - 4321
+    cf3 = [wh.ChannelConfig(mode="wbfm", offset_hz=float(off) + k * 1e5) for k in range(20)]
+    a = wh.ChannelBank(fs, n2, cf3).process(iq[:n2])
+    b = wh.ChannelBank(fs, n2, cf3, iir_form="sequential").process(iq[:n2])
+    assert max(peak_rel_err(a[k][0], b[k][0]) for k in range(20)) <= 1e-6
     # a chain whose poles are too slow for the chunk (or, in ba form at this rate, numerically on the unit circle)
     # stays sequential: warm-up 0 ("never") or longer than half the chunk
     hp = wh.ChannelConfig(mode="nbfm", offset_hz=0.0, enable_deemphasis=False, enable_fm_highpass=True, fm_highpass_hz=300)

@@ -554,6 +554,100 @@ __device__ __forceinline__ void iir_stage(float (*tile)[65], int cnt, int lane, 
     }
 }
 
+// ---- start states of the time-parallel form by the chain's IMPULSE RESPONSE --------------------------------------------
+// The warm-up pass of the time-parallel form runs the recurrences over the `warm` samples before a segment only to get the
+// states at the segment's start.  The chain is linear, so those states are a dot product: with G[d] = the states of all
+// stages d samples after a unit impulse entered the cascade (zero state before), the state after sample st - 1 is
+// sum_d x[st - 1 - d] G[d], d < warm (the same truncation as the warm-up: the response has decayed below 1e-10 by then).
+// m FMAs per sample and stage instead of the recurrence's ~50 dependent operations.  G is produced at bank creation by the
+// recurrences themselves (iir_impulse_kernel: same operations, same float32 roundings between stages).
+__device__ __forceinline__ float iir_step_rt(const StageDev &S, float x, double *z) {
+    const int n = S.n;
+    if (S.is_f64) {
+        const double xd = (double)x;
+        const double y = __dadd_rn(z[0], __dmul_rn(S.b[0], xd));
+        for (int k = 0; k < n - 2; ++k) z[k] = __dsub_rn(__dadd_rn(z[k + 1], __dmul_rn(xd, S.b[k + 1])), __dmul_rn(y, S.a[k + 1]));
+        if (n >= 2) z[n - 2] = __dsub_rn(__dmul_rn(xd, S.b[n - 1]), __dmul_rn(y, S.a[n - 1]));
+        return (float)y;
+    }
+    const float y = __fadd_rn((float)z[0], __fmul_rn((float)S.b[0], x));
+    for (int k = 0; k < n - 2; ++k)
+        z[k] = (double)__fsub_rn(__fadd_rn((float)z[k + 1], __fmul_rn(x, (float)S.b[k + 1])), __fmul_rn(y, (float)S.a[k + 1]));
+    if (n >= 2) z[n - 2] = (double)__fsub_rn(__fmul_rn(x, (float)S.b[n - 1]), __fmul_rn(y, (float)S.a[n - 1]));
+    return y;
+}
+
+// G[d][e], d < warm, e = compact state index (stage 0's states, then stage 1's, ...; row length EP >= the state count,
+// zero padded): one thread walks the cascade over a unit impulse (bank creation, once)
+__global__ void iir_impulse_kernel(StageArr sa, int n_stages, int warm, int EP, double *G) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    double z[MAX_STAGES][MAX_ORD - 1];
+    for (int s = 0; s < MAX_STAGES; ++s)
+        for (int k = 0; k < MAX_ORD - 1; ++k) z[s][k] = 0.0;
+    for (int d = 0; d < warm; ++d) {
+        float v = d == 0 ? 1.0f : 0.0f;
+        for (int s = 0; s < n_stages; ++s) v = iir_step_rt(sa.st[s], v, z[s]);
+        int e = 0;
+        for (int s = 0; s < n_stages; ++s)
+            for (int k = 0; k < sa.st[s].n - 1; ++k) G[(size_t)d * EP + e++] = z[s][k];
+        for (; e < EP; ++e) G[(size_t)d * EP + e] = 0.0;
+    }
+}
+
+// Start states of every segment of every row: S0[row][segment][e] = sum_{d < warm} x[st - 1 - d] G[d][e], st = segment
+// start -- a decimating FIR with the impulse-response states as taps.  Workgroup = 16 segments of one row: wave w takes
+// the segments 4 w .. 4 w + 3 of the group, lane l the delays l, l + 64, ... (a G row is loaded once for the four
+// segments; a wave's lanes read 64 consecutive samples and 64 consecutive G rows), then the lanes are summed by shuffles.
+// The whole chip works on what the warm-up pass did with eight waves per row.
+constexpr int START_SEGS = 16, START_SPT = 4;
+template <int EP>
+__global__ __launch_bounds__(256) void iir_start_kernel(const float *rows, int N, int seg, int warm, int nseg,
+                                                        const double *G, double *S0) {
+    const int r = blockIdx.x, t = threadIdx.x;
+    const int slot = t >> 6, tl = t & 63;
+    const int p0 = blockIdx.y * START_SEGS + START_SPT * slot;
+    const float *x = rows + (size_t)r * N;
+    double acc[START_SPT][EP];
+#pragma unroll
+    for (int q = 0; q < START_SPT; ++q)
+#pragma unroll
+        for (int e = 0; e < EP; ++e) acc[q][e] = 0.0;
+    const long long st0 = (long long)p0 * seg, stl = st0 + (long long)(START_SPT - 1) * seg;
+    if (st0 < N) {
+        const int d_end = stl < warm ? (int)stl : warm;   // delays that still meet a sample of the last segment's past
+#pragma unroll 4
+        for (int d = tl; d < d_end; d += 64) {
+            double xq[START_SPT];
+#pragma unroll
+            for (int q = 0; q < START_SPT; ++q) {
+                // unconditional load from a clamped index, then the select: a conditional load is a branch around the
+                // load, and the loads of a round would no longer be in flight together
+                const long long n = st0 + (long long)q * seg - 1 - d;
+                const long long nc = n < 0 ? 0 : (n >= N ? N - 1 : n);
+                const float xv = x[nc];
+                xq[q] = (n >= 0 && n < N) ? (double)xv : 0.0;   // (a segment starting beyond the row keeps zero states)
+            }
+            const double *g = G + (size_t)d * EP;
+#pragma unroll
+            for (int e = 0; e < EP; ++e) {
+                const double gv = g[e];
+#pragma unroll
+                for (int q = 0; q < START_SPT; ++q) acc[q][e] = fma(xq[q], gv, acc[q][e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < START_SPT; ++q) {
+        const int p = p0 + q;
+#pragma unroll
+        for (int e = 0; e < EP; ++e) {
+            double v = acc[q][e];
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            if (tl == 0 && p < nseg) S0[((size_t)r * nseg + p) * EP + e] = (long long)p * seg < N ? v : 0.0;
+        }
+    }
+}
+
 // One lane per "virtual row"; samples move through an LDS staging tile of ROWS_CH samples x 64 virtual rows: the wave
 // loads it with coalesced 256-byte reads (all 64 lanes on one virtual row at a time), each lane then runs its row
 // through stage after stage (cascading per tile is the same arithmetic as cascading per sample), then the AGC, and the
@@ -571,10 +665,11 @@ __device__ __forceinline__ void iir_stage(float (*tile)[65], int cnt, int lane, 
 constexpr int ROWS_MAXW = 8;
 template <int NS>
 __global__ __launch_bounds__(NS <= 3 ? 64 * ROWS_MAXW : 64) void chan_rows_kernel(float *rows, double *acc, int n_rows, int N, StageArr sa,
-                                                                  AgcDev agc, int seg, int warm) {
+                                                                  AgcDev agc, int seg, int warm, const double *S0, int ep) {
     extern __shared__ __attribute__((aligned(16))) float tile_raw[];   // per wave [ROWS_CH][65]: [sample][row], padded:
     __shared__ StageDev st_s[NS > 0 ? NS : 1];                         // column walks and row walks are conflict-free
     __shared__ double red_s[ROWS_MAXW];
+
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float (*tile)[65] = reinterpret_cast<float (*)[65]>(tile_raw + (size_t)wave * ROWS_CH * 65);
     for (int i = threadIdx.x; i < NS * (int)(sizeof(StageDev) / 4); i += blockDim.x)
@@ -592,7 +687,26 @@ __global__ __launch_bounds__(NS <= 3 ? 64 * ROWS_MAXW : 64) void chan_rows_kerne
     float za = 0.f, zr = 0.f;
     const float NORM = (float)(1.0 / 0.90514825364486640);
     double ss = 0.0;
-    for (int pass = seg ? 0 : 1; pass < 2; ++pass) {
+    // S0 != nullptr: the segments' start states were computed by iir_start_kernel (impulse-response dot product); the
+    // warm-up pass (pass 0) is skipped
+    if (seg && S0 != nullptr && NS > 0) {
+        const int nseg = (int)(blockDim.x >> 6) * 64;
+        const double *src = S0 + ((size_t)r0 * nseg + s0 + lane) * ep;   // compact: stage 0's states, then stage 1's, ...
+        int off = 0;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int m = __builtin_amdgcn_readfirstlane(st_s[s].n) - 1;
+            const bool f64 = st_s[s].is_f64 != 0;
+#pragma unroll
+            for (int k = 0; k < MAX_ORD - 1; ++k)
+                if (k < m) {
+                    const double v = src[off + k];
+                    z[s][k] = f64 ? v : (double)(float)v;   // float32 stages keep float32 states
+                }
+            off += m;
+        }
+    }
+    for (int pass = (seg && S0 == nullptr) ? 0 : 1; pass < 2; ++pass) {
         // virtual row l: offset vo(l) into the buffer, length vn(l)
         // Every lane walks the same number of samples per tile (a scalar trip count in iir_run): the warm-up pass is
         // RIGHT-aligned -- virtual sample i of segment l is chunk sample st - warm + i, zero where that is before the
@@ -1330,6 +1444,9 @@ struct wh_chanbank {
     StageArr stages{};
     ScanPow *d_pow = nullptr;   // scan form: per-stage state-transition powers for the bank's segment length
     int scan_seg = 0, scan_w = 1;   // scan form: segment length, waves per row (64 segments each)
+    double *d_G = nullptr;          // warm-up form: impulse-response states [iir_warmup][start_ep]
+    double *d_S0 = nullptr;         // ... and the segments' start states of a call [rows][segments][start_ep]
+    int start_ep = 0;               // row length of d_G / d_S0: the chain's state count rounded up to even
     double *d_acc = nullptr;
     float *d_fm = nullptr;
     size_t cap_chunks = 0;
@@ -1458,6 +1575,21 @@ extern "C" int wh_chanbank_create(wh_chanbank **out, const wh_chanbank_cfg *c) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_bytes));
         }
     }
+    // warm-up form with the start states from the chain's impulse response (see iir_start_kernel)
+    if (!b->scan_seg && c->iir_warmup_form == 0 && !c->agc && c->iir_warmup > 0 && c->n_stages > 0 &&
+        (c->chunk_len + 63) / 64 + c->iir_warmup <= c->chunk_len / 2) {
+        int E = 0;
+        for (int i = 0; i < c->n_stages; ++i) E += b->stages.st[i].n - 1;
+        const int EP = (E + 1) & ~1;
+        if (E >= 1 && EP <= 16 && c->n_stages <= 3) {   // (longer state vectors keep the recurrence warm-up)
+            b->start_ep = EP;
+            WH_HIP(hipMalloc(&b->d_G, (size_t)c->iir_warmup * EP * sizeof(double)));
+            hipLaunchKernelGGL(iir_impulse_kernel, dim3(1), dim3(1), 0, nullptr, b->stages, c->n_stages, c->iir_warmup, EP,
+                               b->d_G);
+            WH_LAUNCH_CHECK();
+            WH_HIP(hipDeviceSynchronize());
+        }
+    }
     // fused path: plain FM (no IIR stage, no AGC), pure decimation, everything fits in LDS
     b->fused = false;
     if (c->demod == 0 && c->n_stages == 0 && !c->agc && c->post == 0 && !b->nr && resample && c->up == 1 &&
@@ -1493,6 +1625,8 @@ extern "C" void wh_chanbank_destroy(wh_chanbank *b) {
     (void)hipFree(b->d_nco);
     (void)hipFree(b->d_squelch);
     (void)hipFree(b->d_pow);
+    (void)hipFree(b->d_G);
+    (void)hipFree(b->d_S0);
     (void)hipFree(b->d_taps);
     (void)hipFree(b->d_acc);
     (void)hipFree(b->d_fm);
@@ -1535,6 +1669,11 @@ extern "C" int wh_chanbank_run_wire(wh_chanbank *b, const void *d_in, size_t n_c
         b->d_fm = nullptr;
         WH_HIP(hipMalloc(&b->d_acc, rows * 2 * sizeof(double)));
         if (!b->fused && (resample || b->nr)) WH_HIP(hipMalloc(&b->d_fm, rows * (size_t)c.chunk_len * sizeof(float)));
+        if (b->d_G) {
+            (void)hipFree(b->d_S0);
+            b->d_S0 = nullptr;
+            WH_HIP(hipMalloc(&b->d_S0, rows * (size_t)(64 * ROWS_MAXW) * b->start_ep * sizeof(double)));
+        }
         if (b->nr) {
             (void)hipFree(b->d_nr_mag); (void)hipFree(b->d_nr_sel); (void)hipFree(b->d_nr_stft);
             b->d_nr_mag = b->d_nr_sel = nullptr;
@@ -1602,6 +1741,26 @@ extern "C" int wh_chanbank_run_wire(wh_chanbank *b, const void *d_in, size_t n_c
                     seg = (c.chunk_len + 64 * rw - 1) / (64 * rw);
                 }
             }
+            const double *S0 = nullptr;
+            if (seg && b->d_G) {   // start states of all segments, chip-wide (iir_start_kernel)
+                const dim3 sg2((unsigned)rows, (unsigned)((64 * rw + START_SEGS - 1) / START_SEGS));
+#define WH_START(EP_)                                                                                                     \
+    hipLaunchKernelGGL(iir_start_kernel<EP_>, sg2, dim3(256), 0, st, a.fm_out, c.chunk_len, seg, c.iir_warmup, 64 * rw,   \
+                       b->d_G, b->d_S0)
+                switch (b->start_ep) {
+                    case 2: WH_START(2); break;
+                    case 4: WH_START(4); break;
+                    case 6: WH_START(6); break;
+                    case 8: WH_START(8); break;
+                    case 10: WH_START(10); break;
+                    case 12: WH_START(12); break;
+                    case 14: WH_START(14); break;
+                    default: WH_START(16); break;
+                }
+#undef WH_START
+                WH_LAUNCH_CHECK();
+                S0 = b->d_S0;
+            }
             if (b->scan_seg) {
                 hipLaunchKernelGGL(chan_rows_scan_kernel, dim3((unsigned)rows), dim3(64 * b->scan_w),
                                    (size_t)b->scan_w * ROWS_CH * 65 * sizeof(float), st, a.fm_out, b->d_acc, c.chunk_len,
@@ -1616,7 +1775,7 @@ extern "C" int wh_chanbank_run_wire(wh_chanbank *b, const void *d_in, size_t n_c
             WH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chan_rows_kernel<NS_>),                             \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_bytes));                     \
         hipLaunchKernelGGL(chan_rows_kernel<NS_>, rg, dim3(64 * rw), tile_bytes, st, a.fm_out, b->d_acc, (int)rows,       \
-                           c.chunk_len, b->stages, g, seg, c.iir_warmup);                                                 \
+                           c.chunk_len, b->stages, g, seg, c.iir_warmup, S0, b->start_ep);                                \
     } while (0)
             switch (c.n_stages) {
                 case 0: WH_ROWS(0); break;

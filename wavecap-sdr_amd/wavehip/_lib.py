@@ -66,6 +66,7 @@ class ChanBankCfg(C.Structure):
         ("h_nr_window", C.POINTER(c_float)),
         ("iir_warmup", c_int),
         ("iir_scan", c_int),
+        ("iir_warmup_form", c_int),
         ("h_squelch_db", C.POINTER(c_float)),
     ]
 

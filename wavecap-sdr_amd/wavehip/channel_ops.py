@@ -272,7 +272,9 @@ class ChannelBank:
         """apply_squelch=True additionally zeroes the audio of chunks whose rssi_db is below the channel's
         squelch_db (capture.py:2918-2921; in the reference that happens later, in _apply_stateful_processing,
         so the drop-in for _process_channel_dsp_stateless leaves it off).  iir_form="sequential" keeps the IIR stages
-        on the one-lane-per-row recurrence (tests compare the parallel forms against it)."""
+        on the one-lane-per-row recurrence (tests compare the parallel forms against it); "warmup_recurrence" makes
+        the time-parallel warm-up form run the recurrences over its warm-up samples instead of taking the start
+        states from the chain's impulse response (the older, 16x more expensive way to the same states)."""
         if not cfgs:
             raise ValueError("ChannelBank needs at least one channel")
         for c in cfgs:
@@ -303,9 +305,10 @@ class ChannelBank:
             cfg.pll_alpha, cfg.pll_beta = sam_pll_coefficients(self.sample_rate, float(getattr(c0, "sam_pll_bandwidth_hz", 50.0)))
         keep = [offs]
         cfg.n_stages = len(stages)
-        if iir_form not in ("auto", "sequential"):
-            raise ValueError("iir_form must be 'auto' or 'sequential'")
-        par = iir_form == "auto"
+        if iir_form not in ("auto", "sequential", "warmup_recurrence"):
+            raise ValueError("iir_form must be 'auto', 'sequential' or 'warmup_recurrence'")
+        par = iir_form != "sequential"
+        cfg.iir_warmup_form = 1 if iir_form == "warmup_recurrence" else 0
         cfg.iir_warmup = iir_warmup_samples(stages) if (par and stages and agc is None and demod < 3) else 0
         # (the library cuts a row into 64, 256 or 512 segments by channel count: safe for each of them)
         cfg.iir_scan = 1 if (par and all(iir_scan_safe(stages, (self.chunk_len + 64 * w - 1) // (64 * w)) for w in (1, 4, 8))) else 0
