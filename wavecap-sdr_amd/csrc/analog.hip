@@ -169,6 +169,8 @@ struct FmArgs {
     float *audio;       // [n_chunks][K][n_out]   (unscaled FIR output until finalize)
     double *acc;        // [n_chunks][K][2] = {sum |base|^2, sum v^2}
     float *fm_out;      // unfused path: [n_chunks][K][N] demodulated rows
+    const float *rows_src;  // fmbank_fused_kernel as the unfused path's decimating FIR: the window comes from these rows
+                            // ([n_chunks][K][N], already demodulated and filtered) instead of the discriminator
     const float *nco_c; // [K] f32(-2 pi off/fs); 0 => no mix
     const double *taps; // [ntaps]
     int fmt, N, K, n_out, ntaps, down, d0, TO, R;   // R: output tiles per workgroup (fused kernel)
@@ -260,7 +262,16 @@ __global__ __launch_bounds__(256) void fmbank_fused_kernel(FmArgs a) {
         // interior: every sample this pass touches (incl. the idle lanes of its last 63-sample step) exists and is owned
         const bool interior = n_lo + i_lo >= (own_lo > 1 ? own_lo : 1) + 1 && n_lo + W <= own_hi && n_lo + W + 64 <= N;
 #define WH_P1(CHK, F, M) fm_phase1<CHK, F, M>(a, fm_s, i_lo, W, n_lo, N, c, in_base, own_lo, own_hi, lane, wave, p_base, p_fm)
-        if (interior) {
+        if (a.rows_src) {
+            // unfused chains (IIR stages, AGC, AM / SSB fronts): the rows are in memory already; this kernel is their
+            // decimating FIR (the generic one-wave-per-output resampler took 13 of 18 ms for 32 default-config NBFM
+            // channels x 200 chunks)
+            const float *rw = a.rows_src + ((size_t)chunk * a.K + k) * N;
+            for (int i = i_lo + tid; i < W; i += 256) {
+                const int n = n_lo + i;
+                fm_s[i] = (n >= 0 && n < N) ? rw[n] : 0.0f;
+            }
+        } else if (interior) {
             if (a.fmt == 1) { if (do_mix) WH_P1(false, 1, true); else WH_P1(false, 1, false); }
             else            { if (do_mix) WH_P1(false, 0, true); else WH_P1(false, 0, false); }
         } else {
@@ -355,6 +366,7 @@ __global__ __launch_bounds__(256) void fmbank_fused_kernel(FmArgs a) {
             }
         }
     }
+    if (a.rows_src) return;   // (the rows' power sums were taken where the rows were made)
     // block-reduce the two power sums (float64) and publish with one atomic pair
     double db = p_base, df = p_fm;
     for (int o = 32; o > 0; o >>= 1) {
@@ -615,24 +627,70 @@ __global__ __launch_bounds__(256) void iir_start_kernel(const float *rows, int N
     const long long st0 = (long long)p0 * seg, stl = st0 + (long long)(START_SPT - 1) * seg;
     if (st0 < N) {
         const int d_end = stl < warm ? (int)stl : warm;   // delays that still meet a sample of the last segment's past
-#pragma unroll 4
-        for (int d = tl; d < d_end; d += 64) {
-            double xq[START_SPT];
+        // Four delays per round, written out as "all loads, then all FMAs": every load is unconditional (clamped index,
+        // the value zeroed afterwards) so that a round's 28 loads are in flight together -- with a conditional load, or
+        // the loop left to the compiler's unrolling, every delay paid its own memory round trips (1.9 us per delay).
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        // interior groups (every delay of every segment meets a sample of the row, whole rounds): no index clamps, no
+        // selects -- the edge form below spends more instructions on those than on the FMAs
+        const bool interior = st0 - warm >= 0 && stl <= N && d_end == warm;
+        const int d_full = interior ? (warm / 256) * 256 : 0;   // delays covered by whole unchecked rounds
+        const float *xe = x + st0 - 1;
+        for (int d = tl; d < d_full; d += 256) {
+            float xv[4][START_SPT];
+            d2 gv[4][EP / 2];
 #pragma unroll
-            for (int q = 0; q < START_SPT; ++q) {
-                // unconditional load from a clamped index, then the select: a conditional load is a branch around the
-                // load, and the loads of a round would no longer be in flight together
-                const long long n = st0 + (long long)q * seg - 1 - d;
-                const long long nc = n < 0 ? 0 : (n >= N ? N - 1 : n);
-                const float xv = x[nc];
-                xq[q] = (n >= 0 && n < N) ? (double)xv : 0.0;   // (a segment starting beyond the row keeps zero states)
+            for (int u = 0; u < 4; ++u) {
+                const int dd = d + 64 * u;
+#pragma unroll
+                for (int q = 0; q < START_SPT; ++q) xv[u][q] = xe[q * seg - dd];
+                const d2 *g2 = reinterpret_cast<const d2 *>(G + (size_t)dd * EP);
+#pragma unroll
+                for (int e = 0; e < EP / 2; ++e) gv[u][e] = g2[e];
             }
-            const double *g = G + (size_t)d * EP;
 #pragma unroll
-            for (int e = 0; e < EP; ++e) {
-                const double gv = g[e];
+            for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int q = 0; q < START_SPT; ++q) acc[q][e] = fma(xq[q], gv, acc[q][e]);
+                for (int q = 0; q < START_SPT; ++q) {
+                    const double xd = (double)xv[u][q];
+#pragma unroll
+                    for (int e = 0; e < EP / 2; ++e) {
+                        acc[q][2 * e] = fma(xd, gv[u][e].x, acc[q][2 * e]);
+                        acc[q][2 * e + 1] = fma(xd, gv[u][e].y, acc[q][2 * e + 1]);
+                    }
+                }
+        }
+        for (int d = d_full + tl; d < d_end; d += 256) {
+            float xv[4][START_SPT];
+            d2 gv[4][EP / 2];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int dd = d + 64 * u;
+                const int dc = dd < d_end ? dd : tl;          // (a delay past the end re-reads a valid row; its x is zeroed)
+#pragma unroll
+                for (int q = 0; q < START_SPT; ++q) {
+                    const long long n = st0 + (long long)q * seg - 1 - dc;
+                    const long long nc = n < 0 ? 0 : (n >= N ? N - 1 : n);
+                    xv[u][q] = x[nc];
+                }
+                const d2 *g2 = reinterpret_cast<const d2 *>(G + (size_t)dc * EP);   // rows are 16-byte aligned (EP even)
+#pragma unroll
+                for (int e = 0; e < EP / 2; ++e) gv[u][e] = g2[e];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int dd = d + 64 * u;
+#pragma unroll
+                for (int q = 0; q < START_SPT; ++q) {
+                    const long long n = st0 + (long long)q * seg - 1 - dd;
+                    // (a segment starting beyond the row keeps zero states)
+                    const double xd = (dd < d_end && n >= 0 && n < N) ? (double)xv[u][q] : 0.0;
+#pragma unroll
+                    for (int e = 0; e < EP / 2; ++e) {
+                        acc[q][2 * e] = fma(xd, gv[u][e].x, acc[q][2 * e]);
+                        acc[q][2 * e + 1] = fma(xd, gv[u][e].y, acc[q][2 * e + 1]);
+                    }
+                }
             }
         }
     }
@@ -1451,6 +1509,7 @@ struct wh_chanbank {
     float *d_fm = nullptr;
     size_t cap_chunks = 0;
     bool fused = false;
+    bool rows_fir = false;   // unfused chain whose resampler is the fused kernel's decimating FIR
     int TO = 128;
     size_t smem = 0;
     int post = 0;
@@ -1590,10 +1649,11 @@ extern "C" int wh_chanbank_create(wh_chanbank **out, const wh_chanbank_cfg *c) {
             WH_HIP(hipDeviceSynchronize());
         }
     }
-    // fused path: plain FM (no IIR stage, no AGC), pure decimation, everything fits in LDS
+    // fused path: plain FM (no IIR stage, no AGC), pure decimation, everything fits in LDS.  Every other chain with a pure
+    // decimation that fits uses the same kernel as the decimating FIR of its rows (rows_fir).
     b->fused = false;
-    if (c->demod == 0 && c->n_stages == 0 && !c->agc && c->post == 0 && !b->nr && resample && c->up == 1 &&
-        c->ntaps <= FM_MAX_TAPS) {
+    const bool plain_fm = c->demod == 0 && c->n_stages == 0 && !c->agc && c->post == 0;
+    if (!b->nr && resample && c->up == 1 && c->ntaps <= FM_MAX_TAPS) {
         int TO = 256;
         while (TO > 8 && c->ntaps + (TO - 1) * c->down > FM_MAX_SPAN) TO >>= 1;
         // the kernel's 86 VGPRs allow 5 workgroups per CU, LDS only 4 at 128 outputs per tile with the reference's
@@ -1609,7 +1669,8 @@ extern "C" int wh_chanbank_create(wh_chanbank **out, const wh_chanbank_cfg *c) {
             if (bytes(to) <= 32000) TO = to;
         }
         if (c->ntaps + (TO - 1) * c->down <= FM_MAX_SPAN) {
-            b->fused = true;
+            b->fused = plain_fm;
+            b->rows_fir = !plain_fm;
             b->TO = TO;
             b->smem = (size_t)((c->ntaps + 1) & ~1) * sizeof(float) + (size_t)(c->ntaps + 1 + (TO - 1) * c->down) * sizeof(float);
             WH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fmbank_fused_kernel),
@@ -1690,6 +1751,7 @@ extern "C" int wh_chanbank_run_wire(wh_chanbank *b, const void *d_in, size_t n_c
     a.audio = d_audio;
     a.acc = b->d_acc;
     a.fm_out = (resample || b->nr) ? b->d_fm : d_audio;   // no resampling, no length change: rows are the audio
+    a.rows_src = nullptr;
     a.nco_c = b->d_nco;
     a.taps = b->d_taps;
     a.fmt = c.input_format;
@@ -1818,7 +1880,15 @@ extern "C" int wh_chanbank_run_wire(wh_chanbank *b, const void *d_in, size_t n_c
             WH_LAUNCH_CHECK();
         }
         const size_t n_fm = b->nr ? (size_t)b->nr_len : (size_t)c.chunk_len;
-        if (resample) {
+        if (resample && b->rows_fir) {
+            const int tiles = (c.n_out + b->TO - 1) / b->TO;
+            const int R = run_tiles(tiles, rows);
+            a.R = R;
+            a.rows_src = b->d_fm;
+            hipLaunchKernelGGL(fmbank_fused_kernel, dim3((tiles + R - 1) / R, c.n_channels, (unsigned)n_chunks), dim3(256),
+                               b->smem, st, a);
+            WH_LAUNCH_CHECK();
+        } else if (resample) {
             int rc = launch_resample(b->d_fm, n_fm, (size_t)c.chunk_len, rows, d_audio, (size_t)c.n_out, b->d_taps, c.ntaps,
                                      c.up, c.down, c.d0, st);
             if (rc != WH_OK) return rc;
@@ -1855,7 +1925,7 @@ extern "C" int wh_channel_signal_metrics(const void *d_in, int input_format, siz
     WH_HIP(hipMemcpyAsync(d_nco, nco.data(), K * sizeof(float), hipMemcpyHostToDevice, st));
     WH_HIP(hipMemsetAsync(d_acc, 0, (size_t)K * 2 * sizeof(double), st));
     FmArgs a;
-    a.in = d_in; a.audio = nullptr; a.acc = d_acc; a.fm_out = d_rows; a.nco_c = d_nco; a.taps = nullptr;
+    a.in = d_in; a.audio = nullptr; a.acc = d_acc; a.fm_out = d_rows; a.rows_src = nullptr; a.nco_c = d_nco; a.taps = nullptr;
     a.fmt = input_format; a.N = (int)n; a.K = K; a.n_out = 0; a.ntaps = 0; a.down = 1; a.d0 = 0; a.TO = 1; a.R = 1;
     a.scale = 0.f; a.demod = 1; a.bfo_c = 0.0; a.fs_d = (double)sample_rate; a.pll_alpha = a.pll_beta = 0.0;
     const int per_block = 4 * 63 * 16;
