@@ -146,38 +146,59 @@ __global__ __launch_bounds__(TILE) void k_lsm_front(LsmArgs a) {
     y[NT + i] = o;
 }
 
-// The wave-per-channel form of the feedback kernel reads its samples from a REGISTER WINDOW instead of memory: lane l
-// holds P = y[base - 64 + l] and Q = y[base + l] (two coalesced 512-byte loads per 64 samples); sample idx comes out by
-// v_readlane with a wave-uniform lane number.  The look-back of the interpolators is < 32 samples, so two chunks suffice.
-struct LsmWin {
-    float2 P, Q;
-    int base;   // sample index of Q's lane 0 (multiple of 64, relative to the call's first sample; may be negative)
-};
-__device__ __forceinline__ float2 lsm_win_get(const LsmWin &w, int idx) {   // idx wave-uniform, base - 64 <= idx < base + 64
-    const int r = idx - w.base;                  // -64 .. 63
-    const int ln = __builtin_amdgcn_readfirstlane(r & 63);
-    const float2 src = __builtin_amdgcn_readfirstlane(r) >= 0 ? w.Q : w.P;
-    return make_float2(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(src.x), ln)),
-                       __int_as_float(__builtin_amdgcn_readlane(__float_as_int(src.y), ln)));
-}
 // 8-tap MMSE interpolator at look-back `so` from the newest sample; offsets count back in time, offsets < 0 are skipped
-// (p25.py:350).  Operands come from the window / the LDS tap table; products and sums in the reference's order.
-// WAVE = false: one LANE per channel, samples straight from memory (y), taps from the global table.
-template <bool WAVE>
-__device__ __forceinline__ float2 lsm_interp(const float *mmse, const LsmWin &w, const float2 *y, int inew, int so, int imu) {
+// (p25.py:350); products and sums in the reference's order.  One LANE per channel form: samples from memory.
+__device__ __forceinline__ float2 lsm_interp_lane(const float *mmse, const float2 *y, int inew, int so, int imu) {
     float ar = 0.0f, ai = 0.0f;
 #pragma unroll
     for (int tap = 0; tap < 8; ++tap) {
         int off = so + tap - 3;
         if (off < 0 || off >= NT) continue;
         float t = mmse[imu * 8 + tap];
-        float2 v = WAVE ? lsm_win_get(w, inew - off) : y[inew - off];
+        float2 v = y[inew - off];
         float pr = __fsub_rn(__fmul_rn(t, v.x), __fmul_rn(0.0f, v.y));  // (t + 0j) * (a + bj)
         float pi = __fadd_rn(__fmul_rn(t, v.y), __fmul_rn(0.0f, v.x));
         ar = __fadd_rn(ar, pr);
         ai = __fadd_rn(ai, pi);
     }
     return make_float2(ar, ai);
+}
+
+// One WAVE per channel form: the three interpolators of a symbol (now, half a symbol back, a symbol back) side by side.
+// The filtered samples sit in a 128-entry circular LDS window (entry idx & 127; the look-back is < 64); lane 16 j + tap
+// forms product `tap` of interpolator j, and the eight products of an interpolator are summed IN THE REFERENCE'S ORDER by
+// a DPP chain inside its row of 16 lanes: acc <- row_shr:1(acc) + p, eight times -- lane t then holds
+// ((0 + p_0) + p_1) ... + p_t (the shift feeds lane 0 of a row +0.0f, the reference's initial sum).  A skipped tap
+// contributes -0.0f, the identity of float addition (x + -0.0f == x for every x, +-0 included), so the rounding sequence
+// is exactly the reference's with the tap left out.  24 products in one instruction instead of 24 in sequence.
+__device__ __forceinline__ void lsm_interp3_wave(const float *mmse_s, const float2 *win, int inew, int so1, int so2, int imu,
+                                                 int lane, float2 &curr, float2 &mid, float2 &ps) {
+    const int j = lane >> 4, tap = lane & 15;
+    const int so = j == 0 ? 0 : (j == 1 ? so1 : so2);
+    const int off = so + tap - 3;
+    const bool on = j < 3 && tap < 8 && off >= 0 && off < NT;
+    float pr = -0.0f, pi = -0.0f;
+    if (on) {
+        const float t = mmse_s[imu * 8 + tap];
+        const float2 v = win[(inew - off) & 127];
+        pr = __fsub_rn(__fmul_rn(t, v.x), __fmul_rn(0.0f, v.y));  // (t + 0j) * (a + bj)
+        pi = __fadd_rn(__fmul_rn(t, v.y), __fmul_rn(0.0f, v.x));
+    }
+    float ar = 0.0f, ai = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        // row_shr:1 with bound_ctrl: lane t reads lane t - 1 of its row, lane 0 reads 0
+        const float sr = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ar), 0x111, 0xf, 0xf, true));
+        const float si = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ai), 0x111, 0xf, 0xf, true));
+        ar = __fadd_rn(sr, pr);
+        ai = __fadd_rn(si, pi);
+    }
+    curr = make_float2(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(ar), 7)),
+                       __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ai), 7)));
+    mid = make_float2(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(ar), 23)),
+                      __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ai), 23)));
+    ps = make_float2(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(ar), 39)),
+                     __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ai), 39)));
 }
 
 __device__ __forceinline__ float2 lsm_cdiv_real(float2 z, float m) {  // numpy complex64 / (m + 0j)
@@ -199,8 +220,9 @@ __device__ __forceinline__ float lsm_angle(float im, float re) {
 
 // ONE WAVE PER CHANNEL, every lane running the same scalar loop (round 2; one lane per channel before): the loop waits on
 // its own samples -- 24 dependent loads per symbol whose addresses follow the symbol clock (3.2 us per symbol, all of it
-// memory latency) -- so the samples now sit in a register window (LsmWin) and the interpolator taps in LDS.  The
-// arithmetic is untouched (same functions, same order): outputs and carried state stay bit-identical to oracle/lsm_ref.c.
+// memory latency) -- so the samples now sit in an LDS window, the interpolator taps in LDS too, and the 24 products of a
+// symbol's three interpolators are formed by 24 lanes at once (lsm_interp3_wave).  The arithmetic is untouched (same
+// operations, same order of every sum): outputs and carried state stay bit-identical to oracle/lsm_ref.c.
 //
 // WAVE = false is the one-LANE-per-channel form (64 channels per wave, samples from memory): 1.7x slower per call, but a
 // wave carries 64 channels, so beyond ~2000 channels -- where the wave form has filled every SIMD -- it has the higher
@@ -221,12 +243,14 @@ __global__ __launch_bounds__(64) void k_lsm_seq(LsmArgs a) {
     }
     LsmState S = a.st[c];
     const float2 *y = a.filt + (size_t)c * (NT + a.n_max) + NT;
-    // window: Q = samples [0, 64), P = the 64 before (the carried history covers -32 .. -1; older ones are never read)
-    LsmWin w;
-    w.base = 0;
+    // circular window of the filtered samples: entry idx & 127 holds sample idx, idx in [base - 64, base + 64) (the carried
+    // history covers -32 .. -1; older ones are never read)
+    __shared__ float2 win[WAVE ? 128 : 1];
+    int base = 0;
     if constexpr (WAVE) {
-        w.P = lane >= 64 - NT ? y[lane - 64] : make_float2(0.f, 0.f);
-        w.Q = lane < a.n ? y[lane] : make_float2(0.f, 0.f);
+        win[64 + lane] = lane >= 64 - NT ? y[lane - 64] : make_float2(0.f, 0.f);   // (lane - 64) & 127
+        win[lane] = lane < a.n ? y[lane] : make_float2(0.f, 0.f);
+        __builtin_amdgcn_wave_barrier();
     }
     uint8_t *dib = a.dibits + (size_t)c * a.cap;
     float *pho = a.phases ? a.phases + (size_t)c * a.cap : nullptr;
@@ -254,10 +278,11 @@ __global__ __launch_bounds__(64) void k_lsm_seq(LsmArgs a) {
         if (!fire) break;
         const int inew = (WAVE ? __builtin_amdgcn_readfirstlane(i) : i) - 1;   // newest sample of this symbol
         if constexpr (WAVE) {
-            while (inew >= w.base + 64) {                              // slide the register window
-                w.P = w.Q;
-                w.base += 64;
-                w.Q = w.base + lane < a.n ? y[w.base + lane] : make_float2(0.f, 0.f);
+            while (inew >= base + 64) {                                // slide the window
+                base += 64;
+                __builtin_amdgcn_wave_barrier();
+                win[(base + lane) & 127] = base + lane < a.n ? y[base + lane] : make_float2(0.f, 0.f);
+                __builtin_amdgcn_wave_barrier();
             }
         }
         int imu;
@@ -276,7 +301,9 @@ __global__ __launch_bounds__(64) void k_lsm_seq(LsmArgs a) {
         }
         if (imu > 128) imu = 128;
         if (imu < 0) imu = 0;  // NaN clock
-        float2 curr = lsm_interp<WAVE>(mmse, w, y, inew, 0, imu);
+        float2 curr, mid, ps;
+        if constexpr (WAVE) lsm_interp3_wave(mmse, win, inew, a.half_sps, a.full_sps, imu, lane, curr, mid, ps);
+        else curr = lsm_interp_lane(mmse, y, inew, 0, imu);
         float curr_mag = whm_hypotf(curr.x, curr.y);
         int dibit;
         float phase_out;
@@ -329,8 +356,10 @@ __global__ __launch_bounds__(64) void k_lsm_seq(LsmArgs a) {
         }
         ++count;
         if (a.gardner) {
-            float2 mid = lsm_interp<WAVE>(mmse, w, y, inew, a.half_sps, imu);
-            float2 ps = lsm_interp<WAVE>(mmse, w, y, inew, a.full_sps, imu);
+            if constexpr (!WAVE) {
+                mid = lsm_interp_lane(mmse, y, inew, a.half_sps, imu);
+                ps = lsm_interp_lane(mmse, y, inew, a.full_sps, imu);
+            }
             float er = __fsub_rn(curr.x, ps.x), ei = __fsub_rn(curr.y, ps.y);
             float ted = __fsub_rn(__fmul_rn(er, mid.x), __fmul_rn(ei, -mid.y));
             float step = __fmul_rn(0.015f, ted);

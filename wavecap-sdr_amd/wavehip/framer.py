@@ -147,6 +147,7 @@ class P25NIDFrontEnd:
         self._sync = SoftSyncBank(1)
         self._bch = BCHDecoder()
         self.nac_tracker = NACTracker()
+        self._pos_dev = self._cnt_dev = None
         self.reset()
 
     def reset(self) -> None:
@@ -164,8 +165,10 @@ class P25NIDFrontEnd:
         if n == 0 or soft.size != n:
             return []
         scores = self._sync.process_device(torch.from_numpy(soft[None, :]).cuda())
-        pos_dev = torch.empty(n, dtype=torch.int32, device="cuda")
-        cnt_dev = torch.zeros(1, dtype=torch.int32, device="cuda")
+        if self._pos_dev is None or self._pos_dev.numel() < n:      # work buffers live with the object (grow only)
+            self._pos_dev = torch.empty(max(n, 4096), dtype=torch.int32, device="cuda")
+            self._cnt_dev = torch.zeros(1, dtype=torch.int32, device="cuda")
+        pos_dev, cnt_dev = self._pos_dev, self._cnt_dev              # (wh_sync_positions zeroes the counter itself)
         _lib.check(_lib.lib.wh_sync_positions(scores.data_ptr(), n, float(self.SYNC_DETECTION_THRESHOLD),
                                               pos_dev.data_ptr(), n, cnt_dev.data_ptr(), _lib.stream_ptr(torch)),
                    "wh_sync_positions")
