@@ -192,7 +192,7 @@ def _nbfm_valu(el: float, sample_channels: float):
     floor = sample_channels * slots / 64.0 * 4.0 / 1024.0 / 2.4e9
     out = {"algorithmic_valu_slots_per_sample_channel": slots, "algorithmic_valu_floor_ms": round(floor * 1e3, 3),
            "frac_of_algorithmic_valu_floor": round(floor / el, 4)}
-    insts = _profile_counter("fmbank_fused_kernel", "SQ_INSTS_VALU")
+    insts = _profile_counter("fmbank_fused_kernel<false>", "SQ_INSTS_VALU")   # (<true> = the unfused chains' FIR mode)
     if insts:
         issue = insts * 4.0 / 1024.0 / 2.4e9
         out.update({"sq_insts_valu_per_launch": insts, "valu_issue_floor_ms": round(issue * 1e3, 3),

@@ -15,6 +15,7 @@
 #include "wh_common.h"
 #include "wh_portable_math.h"
 #include <cmath>
+#include <type_traits>
 #include <memory>
 #include <vector>
 
@@ -188,40 +189,115 @@ constexpr int FM_MAX_TAPS = 2048;    // float64 taps kept in LDS (16 KiB)
 // output lives in LDS as a window of ntaps + (TO-1)*down samples; after a tile's FIR the window slides by
 // TO*down: its last ntaps-down samples are moved to the front and only the TO*down new ones are computed, so
 // every input sample is mixed / discriminated once per run instead of once per tile that overlaps it.
+typedef float fm_v2f __attribute__((ext_vector_type(2)));
+
+// packed pair of fast_atan2f: same operations per component (the multiplies / FMAs go out as v_pk_* instructions)
+__device__ __forceinline__ fm_v2f fast_atan2f_x2(fm_v2f y, fm_v2f x) {
+    const float PI_F = 3.14159265358979323846f, PIO2_F = 1.57079632679489661923f;
+    const fm_v2f ax = {fabsf(x.x), fabsf(x.y)}, ay = {fabsf(y.x), fabsf(y.y)};
+    const fm_v2f mx = {fmaxf(ax.x, ay.x), fmaxf(ax.y, ay.y)}, mn = {fminf(ax.x, ay.x), fminf(ax.y, ay.y)};
+    const fm_v2f d = mx + fm_v2f{1e-37f, 1e-37f};                 // (0, 0) -> 0
+    const fm_v2f t = mn * fm_v2f{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    const fm_v2f z = t * t;
+#define WH_BC(v) (fm_v2f{(v), (v)})
+    fm_v2f p = WH_BC(-0.004668773151934147f);
+    p = __builtin_elementwise_fma(p, z, WH_BC(0.02416618913412094f));
+    p = __builtin_elementwise_fma(p, z, WH_BC(-0.0593671016395092f));
+    p = __builtin_elementwise_fma(p, z, WH_BC(0.09906096756458282f));
+    p = __builtin_elementwise_fma(p, z, WH_BC(-0.14016585052013397f));
+    p = __builtin_elementwise_fma(p, z, WH_BC(0.19969235360622406f));
+    p = __builtin_elementwise_fma(p, z, WH_BC(-0.33331960439682007f));
+    p = __builtin_elementwise_fma(p, z, WH_BC(0.9999998807907104f));
+#undef WH_BC
+    fm_v2f r = p * t;
+    r.x = ay.x > ax.x ? PIO2_F - r.x : r.x;
+    r.y = ay.y > ax.y ? PIO2_F - r.y : r.y;
+    r.x = x.x < 0.0f ? PI_F - r.x : r.x;
+    r.y = x.y < 0.0f ? PI_F - r.y : r.y;
+    return fm_v2f{__builtin_copysignf(r.x, y.x), __builtin_copysignf(r.y, y.y)};
+}
+
+// Phase 1 of the fused kernel, TWO samples per lane: lane l of a wave takes the window indices s0 + 2l - 1 and s0 + 2l (a
+// wave advances 127 samples per step; lane 0's first sample only supplies x[n-1]).  The previous sample of the second one
+// is the lane's own first, that of the first one the neighbour's second (one shuffle per two samples), both samples of
+// int16 input come in with one 8-byte load, and the NCO / mix / discriminator / atan2 arithmetic of the pair goes out as
+// packed instructions.  Per sample the operations are those of the one-sample form (same results for a sample whichever
+// slot computes it): 87 -> about 65 issue slots per sample and channel.
 template <bool CHECK, int FMT, bool MIX>
 __device__ __forceinline__ void fm_phase1(const FmArgs &a, float *fm_s, int i_lo, int i_hi, int n_lo, int N, float c,
                                           size_t in_base, int own_lo, int own_hi, int lane, int wave,
                                           double &p_base, double &p_fm) {
-    // each wave covers 63 samples per step; lane 0 only supplies x[n-1]
-    for (int s0 = i_lo + wave * 63; s0 < i_hi; s0 += 4 * 63) {
-        const int i = s0 + lane - 1;    // window index (lane 0 -> previous sample)
-        const int n = n_lo + i;         // chunk sample index
-        const bool valid = !CHECK || ((n >= 0) && (n < N));
-        float2 bse = make_float2(0.f, 0.f);
-        if (valid) {
-            bse = load_iq(a.in, FMT, in_base + n);
-            if (MIX) bse = mix_fast(bse, c, n);
-        }
-        float2 prv;
-        prv.x = __shfl_up(bse.x, 1);
-        prv.y = __shfl_up(bse.y, 1);
-        if (lane > 0 && i < i_hi) {
-            float v = 0.f;
-            if (valid && (!CHECK || n >= 1)) {
-                float re = bse.x * prv.x + bse.y * prv.y;
-                float im = bse.y * prv.x - bse.x * prv.y;
-                v = fast_atan2f(im, re) * a.scale;
+    // interior passes (no bounds checks) load one step ahead: the pair of the NEXT step is in flight while this one is
+    // mixed and discriminated (the last step re-reads its own pair)
+    typedef typename std::conditional<FMT == 1, short4, float4>::type raw_t;   // two IQ pairs, 4-byte aligned
+    const char *in_b = reinterpret_cast<const char *>(a.in) + (in_base + (size_t)n_lo) * (FMT == 1 ? 4 : 8);
+    raw_t q_next;
+    if (!CHECK && i_lo + wave * 127 < i_hi)
+        __builtin_memcpy(&q_next, in_b + (long long)(i_lo + wave * 127 + 2 * lane - 1) * (FMT == 1 ? 4 : 8), sizeof(q_next));
+    for (int s0 = i_lo + wave * 127; s0 < i_hi; s0 += 4 * 127) {
+        const int ia = s0 + 2 * lane - 1, ib = ia + 1;   // window indices
+        const int na = n_lo + ia, nb = na + 1;           // chunk sample indices
+        const bool va = !CHECK || ((na >= 0) && (na < N)), vb = !CHECK || ((nb >= 0) && (nb < N));
+        fm_v2f bx = {0.f, 0.f}, by = {0.f, 0.f};         // (re of a, re of b), (im of a, im of b)
+        if (!CHECK) {
+            const raw_t q = q_next;
+            const int sn = s0 + 4 * 127 < i_hi ? s0 + 4 * 127 : s0;
+            __builtin_memcpy(&q_next, in_b + (long long)(sn + 2 * lane - 1) * (FMT == 1 ? 4 : 8), sizeof(q_next));
+            if (FMT == 1) {
+                bx = fm_v2f{(float)q.x, (float)q.z} * fm_v2f{1.0f / 32768.0f, 1.0f / 32768.0f};   // A1 unpack rule (exact)
+                by = fm_v2f{(float)q.y, (float)q.w} * fm_v2f{1.0f / 32768.0f, 1.0f / 32768.0f};
+            } else {
+                bx = fm_v2f{(float)q.x, (float)q.z};
+                by = fm_v2f{(float)q.y, (float)q.w};
             }
-            fm_s[i] = v;
-            if (!CHECK || (valid && n >= own_lo && n < own_hi)) {
+        } else {
+            if (va) { const float2 v = load_iq(a.in, FMT, in_base + na); bx.x = v.x; by.x = v.y; }
+            if (vb) { const float2 v = load_iq(a.in, FMT, in_base + nb); bx.y = v.x; by.y = v.y; }
+        }
+        if (MIX) {   // mix_fast on the pair
+            const fm_v2f C_HI = {0.15915494f, 0.15915494f}, C_LO = {6.4206382e-09f, 6.4206382e-09f};
+            const fm_v2f ph = fm_v2f{c, c} * fm_v2f{(float)na, (float)nb};
+            const fm_v2f t_hi = ph * C_HI;
+            const fm_v2f t_lo = __builtin_elementwise_fma(ph, C_LO, __builtin_elementwise_fma(ph, C_HI, -t_hi));
+            const fm_v2f fr = fm_v2f{__builtin_amdgcn_fractf(t_hi.x), __builtin_amdgcn_fractf(t_hi.y)} + t_lo;
+            const fm_v2f sn = {__builtin_amdgcn_sinf(fr.x), __builtin_amdgcn_sinf(fr.y)};
+            const fm_v2f co = {__builtin_amdgcn_cosf(fr.x), __builtin_amdgcn_cosf(fr.y)};
+            const fm_v2f mr = __builtin_elementwise_fma(bx, co, -(by * sn));
+            const fm_v2f mi = __builtin_elementwise_fma(bx, sn, by * co);
+            // (an invalid sample is (0, 0) before and after the rotation)
+            bx = mr;
+            by = mi;
+        }
+        // previous samples: of a the neighbour lane's b, of b the lane's own a
+        const fm_v2f px = {__shfl_up(bx.y, 1), bx.x}, py = {__shfl_up(by.y, 1), by.x};
+        const fm_v2f re = __builtin_elementwise_fma(bx, px, by * py);
+        const fm_v2f im = __builtin_elementwise_fma(by, px, -(bx * py));
+        fm_v2f v = fast_atan2f_x2(im, re) * fm_v2f{a.scale, a.scale};
+        if (CHECK) {
+            if (!(va && na >= 1)) v.x = 0.f;
+            if (!(vb && nb >= 1)) v.y = 0.f;
+        }
+        const fm_v2f pw = __builtin_elementwise_fma(bx, bx, by * by);
+        if (lane > 0 && ia < i_hi) {
+            fm_s[ia] = v.x;
+            if (!CHECK || (va && na >= own_lo && na < own_hi)) {
                 // float64 running sums: the result must not depend on how a row is cut into runs (batch size)
-                p_base += (double)(bse.x * bse.x + bse.y * bse.y);
-                p_fm += (double)(v * v);
+                p_base += (double)pw.x;
+                p_fm += (double)(v.x * v.x);
+            }
+        }
+        if (ib < i_hi) {
+            fm_s[ib] = v.y;
+            if (!CHECK || (vb && nb >= own_lo && nb < own_hi)) {
+                p_base += (double)pw.y;
+                p_fm += (double)(v.y * v.y);
             }
         }
     }
 }
 
+// ROWS: the unfused chains' decimating FIR (the window is copied from a.rows_src instead of computed by phase 1)
+template <bool ROWS>
 __global__ __launch_bounds__(256) void fmbank_fused_kernel(FmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float *taps_s = reinterpret_cast<float *>(smem_raw);                       // taps rounded to float32, reversed
@@ -259,10 +335,10 @@ __global__ __launch_bounds__(256) void fmbank_fused_kernel(FmArgs a) {
         const int n_lo = m0 * a.down + a.d0 - (a.ntaps - 1);   // chunk index of window slot 0
         // phase 1: the whole window for the first tile of the run, the new part afterwards
         const int i_lo = (tile == t_lo || keep <= 0) ? 0 : keep;
-        // interior: every sample this pass touches (incl. the idle lanes of its last 63-sample step) exists and is owned
-        const bool interior = n_lo + i_lo >= (own_lo > 1 ? own_lo : 1) + 1 && n_lo + W <= own_hi && n_lo + W + 64 <= N;
+        // interior: every sample this pass touches (incl. the idle lanes of its last 127-sample step) exists and is owned
+        const bool interior = n_lo + i_lo >= (own_lo > 1 ? own_lo : 1) + 1 && n_lo + W <= own_hi && n_lo + W + 128 <= N;
 #define WH_P1(CHK, F, M) fm_phase1<CHK, F, M>(a, fm_s, i_lo, W, n_lo, N, c, in_base, own_lo, own_hi, lane, wave, p_base, p_fm)
-        if (a.rows_src) {
+        if (ROWS) {
             // unfused chains (IIR stages, AGC, AM / SSB fronts): the rows are in memory already; this kernel is their
             // decimating FIR (the generic one-wave-per-output resampler took 13 of 18 ms for 32 default-config NBFM
             // channels x 200 chunks)
@@ -366,7 +442,7 @@ __global__ __launch_bounds__(256) void fmbank_fused_kernel(FmArgs a) {
             }
         }
     }
-    if (a.rows_src) return;   // (the rows' power sums were taken where the rows were made)
+    if (ROWS) return;   // (the rows' power sums were taken where the rows were made)
     // block-reduce the two power sums (float64) and publish with one atomic pair
     double db = p_base, df = p_fm;
     for (int o = 32; o > 0; o >>= 1) {
@@ -1673,7 +1749,9 @@ extern "C" int wh_chanbank_create(wh_chanbank **out, const wh_chanbank_cfg *c) {
             b->rows_fir = !plain_fm;
             b->TO = TO;
             b->smem = (size_t)((c->ntaps + 1) & ~1) * sizeof(float) + (size_t)(c->ntaps + 1 + (TO - 1) * c->down) * sizeof(float);
-            WH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fmbank_fused_kernel),
+            WH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fmbank_fused_kernel<false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->smem));
+            WH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fmbank_fused_kernel<true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->smem));
         }
     }
@@ -1773,7 +1851,7 @@ extern "C" int wh_chanbank_run_wire(wh_chanbank *b, const void *d_in, size_t n_c
         const int tiles = (c.n_out + b->TO - 1) / b->TO;
         const int R = run_tiles(tiles, rows);
         a.R = R;
-        hipLaunchKernelGGL(fmbank_fused_kernel, dim3((tiles + R - 1) / R, c.n_channels, (unsigned)n_chunks), dim3(256),
+        hipLaunchKernelGGL(fmbank_fused_kernel<false>, dim3((tiles + R - 1) / R, c.n_channels, (unsigned)n_chunks), dim3(256),
                            b->smem, st, a);
         WH_LAUNCH_CHECK();
     } else {
@@ -1885,7 +1963,7 @@ extern "C" int wh_chanbank_run_wire(wh_chanbank *b, const void *d_in, size_t n_c
             const int R = run_tiles(tiles, rows);
             a.R = R;
             a.rows_src = b->d_fm;
-            hipLaunchKernelGGL(fmbank_fused_kernel, dim3((tiles + R - 1) / R, c.n_channels, (unsigned)n_chunks), dim3(256),
+            hipLaunchKernelGGL(fmbank_fused_kernel<true>, dim3((tiles + R - 1) / R, c.n_channels, (unsigned)n_chunks), dim3(256),
                                b->smem, st, a);
             WH_LAUNCH_CHECK();
         } else if (resample) {
