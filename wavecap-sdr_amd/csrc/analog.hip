@@ -1811,7 +1811,10 @@ extern "C" int wh_chanbank_run_wire(wh_chanbank *b, const void *d_in, size_t n_c
         if (b->d_G) {
             (void)hipFree(b->d_S0);
             b->d_S0 = nullptr;
-            WH_HIP(hipMalloc(&b->d_S0, rows * (size_t)(64 * ROWS_MAXW) * b->start_ep * sizeof(double)));
+            // (segments per row: the warm-up form's wave count is a property of the bank, see below)
+            int rw = c.n_stages > 3 ? 1 : c.n_channels <= 16 ? ROWS_MAXW : c.n_channels <= 64 ? 4 : 1;
+            while (rw > 1 && c.chunk_len < 64 * rw * 16) rw >>= 1;
+            WH_HIP(hipMalloc(&b->d_S0, rows * (size_t)(64 * rw) * b->start_ep * sizeof(double)));
         }
         if (b->nr) {
             (void)hipFree(b->d_nr_mag); (void)hipFree(b->d_nr_sel); (void)hipFree(b->d_nr_stft);
