@@ -580,7 +580,12 @@ struct StageArr {
 // stage's dtype; the next sample is fetched from LDS while the current one walks the recurrence.
 constexpr int ROWS_CH = 64;
 
-template <int NC, bool F64, bool UNI = false>
+// FUSED: the state updates as fused multiply-adds (half the float64 issue slots of the loop).  Only the time-parallel form
+// uses it: it serves chains whose recurrences are well conditioned (their impulse responses die out inside the chunk), where
+// one rounding more or less per update is far below the float32 output, and it is not bit-comparable with the sequential
+// recurrence anyway (its start states are truncated sums).  The sequential form -- the only one the reference's
+// ill-conditioned ba-form high-passes can take -- keeps scipy's operation order exactly.
+template <int NC, bool F64, bool UNI = false, bool FUSED = false>
 __device__ __forceinline__ void iir_run(float (*tile)[65], int cnt, int lane, double (&z)[MAX_ORD - 1], const StageDev &S) {
     // S lives in LDS: the coefficients arrive in VGPRs (read from the scalar kernarg copy the compiler keeps them in
     // SGPRs, runs out of those and round-trips them through v_readlane inside the sample loop)
@@ -588,13 +593,26 @@ __device__ __forceinline__ void iir_run(float (*tile)[65], int cnt, int lane, do
 #pragma unroll
     for (int k = 0; k < NC; ++k) { b[k] = S.b[k]; a[k] = S.a[k]; }
     auto step = [&](float x) -> float {
-        if (F64) {
+        if (F64 && FUSED) {
+            const double xd = (double)x;
+            const double y = fma(b[0], xd, z[0]);
+#pragma unroll
+            for (int k = 0; k < NC - 2; ++k) z[k] = fma(-y, a[k + 1], fma(xd, b[k + 1], z[k + 1]));
+            if (NC >= 2) z[NC - 2] = fma(-y, a[NC - 1], xd * b[NC - 1]);
+            return (float)y;
+        } else if (F64) {
             const double xd = (double)x;
             const double y = __dadd_rn(z[0], __dmul_rn(b[0], xd));
 #pragma unroll
             for (int k = 0; k < NC - 2; ++k) z[k] = __dsub_rn(__dadd_rn(z[k + 1], __dmul_rn(xd, b[k + 1])), __dmul_rn(y, a[k + 1]));
             if (NC >= 2) z[NC - 2] = __dsub_rn(__dmul_rn(xd, b[NC - 1]), __dmul_rn(y, a[NC - 1]));
             return (float)y;
+        } else if (FUSED) {
+            const float y = fmaf((float)b[0], x, (float)z[0]);
+#pragma unroll
+            for (int k = 0; k < NC - 2; ++k) z[k] = (double)fmaf(-y, (float)a[k + 1], fmaf(x, (float)b[k + 1], (float)z[k + 1]));
+            if (NC >= 2) z[NC - 2] = (double)fmaf(-y, (float)a[NC - 1], x * (float)b[NC - 1]);
+            return y;
         } else {
             const float y = __fadd_rn((float)z[0], __fmul_rn((float)b[0], x));
 #pragma unroll
@@ -625,20 +643,20 @@ __device__ __forceinline__ void iir_run(float (*tile)[65], int cnt, int lane, do
     }
 }
 
-template <bool F64, bool UNI = false>
+template <bool F64, bool UNI = false, bool FUSED = false>
 __device__ __forceinline__ void iir_stage(float (*tile)[65], int cnt, int lane, double (&z)[MAX_ORD - 1], const StageDev &S) {
     switch (__builtin_amdgcn_readfirstlane(S.n)) {   // wave-uniform, once per (tile, stage)
-        case 1: iir_run<1, F64, UNI>(tile, cnt, lane, z, S); break;
-        case 2: iir_run<2, F64, UNI>(tile, cnt, lane, z, S); break;
-        case 3: iir_run<3, F64, UNI>(tile, cnt, lane, z, S); break;
-        case 4: iir_run<4, F64, UNI>(tile, cnt, lane, z, S); break;
-        case 5: iir_run<5, F64, UNI>(tile, cnt, lane, z, S); break;
-        case 6: iir_run<6, F64, UNI>(tile, cnt, lane, z, S); break;
-        case 7: iir_run<7, F64, UNI>(tile, cnt, lane, z, S); break;
-        case 8: iir_run<8, F64, UNI>(tile, cnt, lane, z, S); break;
-        case 9: iir_run<9, F64, UNI>(tile, cnt, lane, z, S); break;
-        case 10: iir_run<10, F64, UNI>(tile, cnt, lane, z, S); break;
-        default: iir_run<11, F64, UNI>(tile, cnt, lane, z, S); break;
+        case 1: iir_run<1, F64, UNI, FUSED>(tile, cnt, lane, z, S); break;
+        case 2: iir_run<2, F64, UNI, FUSED>(tile, cnt, lane, z, S); break;
+        case 3: iir_run<3, F64, UNI, FUSED>(tile, cnt, lane, z, S); break;
+        case 4: iir_run<4, F64, UNI, FUSED>(tile, cnt, lane, z, S); break;
+        case 5: iir_run<5, F64, UNI, FUSED>(tile, cnt, lane, z, S); break;
+        case 6: iir_run<6, F64, UNI, FUSED>(tile, cnt, lane, z, S); break;
+        case 7: iir_run<7, F64, UNI, FUSED>(tile, cnt, lane, z, S); break;
+        case 8: iir_run<8, F64, UNI, FUSED>(tile, cnt, lane, z, S); break;
+        case 9: iir_run<9, F64, UNI, FUSED>(tile, cnt, lane, z, S); break;
+        case 10: iir_run<10, F64, UNI, FUSED>(tile, cnt, lane, z, S); break;
+        default: iir_run<11, F64, UNI, FUSED>(tile, cnt, lane, z, S); break;
     }
 }
 
@@ -884,8 +902,15 @@ __global__ __launch_bounds__(NS <= 3 ? 64 * ROWS_MAXW : 64) void chan_rows_kerne
             {
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
-                    if (sa.st[s].is_f64) iir_stage<true, true>(tile, cntu, lane, z[s], st_s[s]);
-                    else iir_stage<false, true>(tile, cntu, lane, z[s], st_s[s]);
+                    // time-parallel form of the short chains: fused updates (see iir_run; longer chains keep one code
+                    // path -- both would not unroll, and z[s] must stay in registers)
+                    if (NS <= 3 && seg) {
+                        if (sa.st[s].is_f64) iir_stage<true, true, true>(tile, cntu, lane, z[s], st_s[s]);
+                        else iir_stage<false, true, true>(tile, cntu, lane, z[s], st_s[s]);
+                    } else {
+                        if (sa.st[s].is_f64) iir_stage<true, true>(tile, cntu, lane, z[s], st_s[s]);
+                        else iir_stage<false, true>(tile, cntu, lane, z[s], st_s[s]);
+                    }
                 }
                 if (agc.on) {
                     for (int j = 0; j < cnt; ++j) {
