@@ -4,8 +4,9 @@
 //
 // fmbank fused kernel (up == 1, nbfm): one workgroup = (chunk, channel, tile of TO outputs).
 //   phase 1  NCO mix + discriminator for the tile's span of input samples, straight from the
-//            shared int16 / complex64 chunk (coalesced), neighbour sample x[n-1] taken from the
-//            previous lane with a wavefront shuffle (each wave advances 63 samples), fm kept in LDS;
+//            shared int16 / complex64 chunk (coalesced), two samples per lane in packed arithmetic, the
+//            neighbour sample x[n-1] of a lane's first sample taken from the previous lane with a wavefront
+//            shuffle (each wave advances 127 samples per step, loads one step ahead), fm kept in LDS;
 //   phase 2  the decimating FIR (resample_poly taps, float64 accumulation like scipy) computed
 //            only at the kept outputs, from LDS;
 //   the RMS normalisation commutes with the FIR, so its scale (which needs the whole chunk) and
