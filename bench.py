@@ -141,7 +141,7 @@ def _profile_counter(kernel_substr: str, counter: str):
     return None
 
 
-def secondary_nbfm(torch, steps: int = 5):
+def secondary_nbfm(torch, steps: int = 10):
     """BASELINE configs[1]: 32 NBFM channels from one 2.4 MS/s int16-IQ stream, 10 s = 200 chunks of
     120 000 samples per step, one fused launch.  Returns MS/s x channels + the CPU oracle beside it."""
     import numpy as np
@@ -158,7 +158,8 @@ def secondary_nbfm(torch, steps: int = 5):
     d_in = torch.from_numpy(np.tile(i16_chunk, chunks)).cuda()
     audio = torch.empty((chunks, K, bank.n_out), dtype=torch.float32, device="cuda")
     met = torch.empty((chunks, K, 4), dtype=torch.float32, device="cuda")
-    bank.process_device(d_in, chunks, audio, met)
+    for _ in range(3):                       # (the first call grows the workspace)
+        bank.process_device(d_in, chunks, audio, met)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
