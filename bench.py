@@ -257,9 +257,22 @@ def secondary_pfb_int16(torch, steps: int = 10):
         torch.cuda.synchronize()
         ms.append(ch.last_kernel_ms())
     k = sorted(ms)[len(ms) // 2]
+    # yardstick: the same 1 : 4 read : write byte stream with no arithmetic (4 B in, 16 B out per sample)
+    from wavehip import _lib as _wl
+    del out
+    xin = torch.empty(n // 2, 2, dtype=torch.float32, device="cuda").normal_()      # n/2 complex64 = 4 B per sample
+    yo = torch.empty(2 * n, dtype=torch.complex64, device="cuda")                    # four copies = 16 B per sample
+    for _ in range(3):
+        _wl.check(_wl.lib.wh_diag_stream_1r4w(xin.data_ptr(), yo.data_ptr(), n // 2, _wl.stream_ptr(torch)), "diag")
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10):
+        _wl.check(_wl.lib.wh_diag_stream_1r4w(xin.data_ptr(), yo.data_ptr(), n // 2, _wl.stream_ptr(torch)), "diag")
+    torch.cuda.synchronize()
+    ys = 20.0 * n / ((time.perf_counter() - t0) / 10) / 1e9
     return {"workload": "1024-channel filterbank, int16 IQ input, 2^28 samples per launch", "kernel_ms": round(k, 4),
             "input_msps": round(n / k / 1e3, 1), "algorithmic_GBps": round(20.0 * n / k / 1e6, 1),
-            "frac_of_8TBps": round(20.0 * n / k / 1e6 / 8000.0, 4)}
+            "frac_of_8TBps": round(20.0 * n / k / 1e6 / 8000.0, 4), "stream_1r4w_yardstick_GBps": round(ys, 1),
+            "frac_of_stream_yardstick": round(20.0 * n / k / 1e6 / ys, 4)}
 
 
 def secondary_pfb_stats(torch, steps: int = 10):

@@ -214,6 +214,8 @@ int wh_stats_merge(const double *d_gathered, int n_ranks, int n_channels, double
  * from d_in, writes them twice (2n complex64) to d_out; n even.  bench.py times it beside the filterbank as the
  * in-process yardstick for a 1 : 2 read : write stream. */
 int wh_diag_stream_1r2w(const float *d_in, float *d_out, size_t n, void *stream);
+/* the same with FOUR copies written (4n complex64 to d_out): the 1 : 4 read : write stream of the int16-input filterbank */
+int wh_diag_stream_1r4w(const float *d_in, float *d_out, size_t n, void *stream);
 
 /* ---- A8: spectrum, dsp/fft/scipy_backend.py:38-79 ScipyFFTBackend.execute ---------
  * d_iq: complex64, frame f starts at d_iq + f*frame_stride (complex units); uses the

@@ -1126,6 +1126,12 @@ def test_diag_stream_yardstick_copies_twice(wh):
         torch.cuda.synchronize()
         assert torch.equal(y[:n], x) and torch.equal(y[n:], x)
     assert _lib.lib.wh_diag_stream_1r2w(x.data_ptr(), y.data_ptr(), 3, None) != 0
+    for n in (2, 4096 * 3 + 6):                      # the 1 : 4 form (the int16-input filterbank's traffic shape)
+        x = torch.view_as_complex(torch.randn(n, 2, device="cuda"))
+        y = torch.zeros(4 * n, dtype=torch.complex64, device="cuda")
+        _lib.check(_lib.lib.wh_diag_stream_1r4w(x.data_ptr(), y.data_ptr(), n, _lib.stream_ptr(torch)), "diag")
+        torch.cuda.synchronize()
+        assert all(torch.equal(y[k * n:(k + 1) * n], x) for k in range(4))
 
 
 def test_operator_from_a_thread_pool(wh, golden):

@@ -1208,6 +1208,37 @@ extern "C" int wh_diag_stream_1r2w(const float *d_in, float *d_out, size_t n, vo
     return WH_OK;
 }
 
+// the int16 filterbank's traffic shape: n complex64-sized reads of 4 bytes each would be n float2 halves -- here n float
+// pairs (8 bytes) are read and written FOUR times (1 : 4 read : write, like 4 B in / 16 B out per sample)
+__global__ __launch_bounds__(256) void stream_1r4w_kernel(const float4 *in, float4 *out, size_t n4) {
+    const size_t stride = (size_t)gridDim.x * 256 * 4;
+    for (size_t i0 = (size_t)blockIdx.x * 256 * 4 + threadIdx.x; i0 < n4; i0 += stride) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = i0 + u * 256 < n4 ? in[i0 + u * 256] : make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u * 256 < n4) {
+                const size_t i = i0 + u * 256;
+                out[i] = v[u];
+                out[n4 + i] = v[u];
+                out[2 * n4 + i] = v[u];
+                out[3 * n4 + i] = v[u];
+            }
+    }
+}
+
+extern "C" int wh_diag_stream_1r4w(const float *d_in, float *d_out, size_t n, void *stream) {
+    if (!d_in || !d_out || (n & 1)) return set_err(WH_E_ARG, "wh_diag_stream_1r4w: null buffer or odd n");
+    if (n == 0) return WH_OK;
+    const size_t n4 = n / 2;
+    const size_t blocks = (n4 + 1023) / 1024;   // one pass per workgroup, as wh_diag_stream_1r2w
+    hipLaunchKernelGGL(stream_1r4w_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float4 *>(d_in), reinterpret_cast<float4 *>(d_out), n4);
+    WH_LAUNCH_CHECK();
+    return WH_OK;
+}
+
 extern "C" int wh_pfb_run_stats(wh_pfb *p, const void *d_iq, int input_format, size_t n, double *d_stats, int accumulate,
                                 void *stream) {
     if (!p) return set_err(WH_E_ARG, "wh_pfb_run_stats: null handle");

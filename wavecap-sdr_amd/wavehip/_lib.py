@@ -126,6 +126,7 @@ PROTOTYPES = {
     "wh_pfb_extract_channel": (c_int, [c_void_p, c_size_t, c_int, c_int, c_void_p, c_void_p]),
     "wh_pfb_channel_stats": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_void_p]),
     "wh_diag_stream_1r2w": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wh_diag_stream_1r4w": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "wh_pfb_destroy": (None, [c_void_p]),
     "wh_spectrum_create": (c_int, [C.POINTER(c_void_p), c_int]),
     "wh_spectrum_run": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p]),
