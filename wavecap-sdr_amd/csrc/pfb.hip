@@ -99,12 +99,16 @@ __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
     if (g1 > a.n_groups) g1 = a.n_groups;
     if (g0 >= g1) return;
 
-    // taps: arms[k][j] for k = t, t+256, t+512, t+768
-    float tap[4][FT];
+    // taps: arms[k][j] for k = t, t+256, t+512, t+768, kept as 18 register PAIRS (tap e = q * 9 + j is half e & 1 of pair
+    // e / 2): the arm MAC below is packed -- (re, im) * tap as one v_pk_fma_f32 with the tap broadcast from its half of the
+    // pair through op_sel -- half the instructions of the scalar form
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f tpr[(4 * FT) / 2];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int j = 0; j < FT; ++j) tap[q][j] = a.arms[(t + 256 * q) * FT + j];
+    for (int e = 0; e < 4 * FT; e += 2) {
+        const int q0 = e / FT, j0 = e - q0 * FT, q1 = (e + 1) / FT, j1 = (e + 1) - q1 * FT;
+        tpr[e / 2] = v2f{a.arms[(t + 256 * q0) * FT + j0], a.arms[(t + 256 * q1) * FT + j1]};
+    }
 
     // stage-1 twiddles W1024^(t*k1), k1 = 1..3
     float2 tw1 = a.tw1024[t], tw2 = a.tw1024[(2 * t) & 1023], tw3 = a.tw1024[(3 * t) & 1023];
@@ -132,23 +136,25 @@ __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
     for (long long g = g0; g < g1; ++g, h += GH) {
         unsigned char *pre = pre0 + (((g - g0) & 1) ? PRE_BYTES : 0);   // buffer of the copy issued in this iteration
         // ---- arm MAC + radix-4 stage for GH hops --------------------------------------------
+        // (the pairs stay PAIRS: seen through, the compiler keeps a broadcast {t, t} copy of every tap -- 72 registers)
+#pragma unroll
+        for (int e = 0; e < (4 * FT) / 2; ++e) asm volatile("" : "+v"(tpr[e]));
+#define WH_TAP(q, j) ((((q) * FT + (j)) & 1) ? __builtin_shufflevector(tpr[((q) * FT + (j)) >> 1], tpr[((q) * FT + (j)) >> 1], 1, 1) \
+                                             : __builtin_shufflevector(tpr[((q) * FT + (j)) >> 1], tpr[((q) * FT + (j)) >> 1], 0, 0))
+#define WH_V2(f) (v2f{(f).x, (f).y})
 #pragma unroll
         for (int i = 0; i < GH; ++i) {
             // hop h+i: y[k0] uses c_{h+i-j} = w[i+8-j]; y[k0+512] uses c_{h+i-j+1} = w[i+9-j]
-            float2 y0 = make_float2(0.f, 0.f), y1 = y0, y2 = y0, y3 = y0;
+            v2f p0 = {0.f, 0.f}, p1 = p0, p2 = p0, p3 = p0;
 #pragma unroll
             for (int j = 0; j < FT; ++j) {
-                float2 ca = wA[i + 8 - j], cb = wB[i + 8 - j];
-                float2 ca1 = wA[i + 9 - j], cb1 = wB[i + 9 - j];
-                y0.x = fmaf(ca.x, tap[0][j], y0.x);
-                y0.y = fmaf(ca.y, tap[0][j], y0.y);   // k = t
-                y1.x = fmaf(cb.x, tap[1][j], y1.x);
-                y1.y = fmaf(cb.y, tap[1][j], y1.y);   // k = t+256
-                y2.x = fmaf(ca1.x, tap[2][j], y2.x);
-                y2.y = fmaf(ca1.y, tap[2][j], y2.y);  // k = t+512
-                y3.x = fmaf(cb1.x, tap[3][j], y3.x);
-                y3.y = fmaf(cb1.y, tap[3][j], y3.y);  // k = t+768
+                p0 = __builtin_elementwise_fma(WH_V2(wA[i + 8 - j]), WH_TAP(0, j), p0);   // k = t
+                p1 = __builtin_elementwise_fma(WH_V2(wB[i + 8 - j]), WH_TAP(1, j), p1);   // k = t+256
+                p2 = __builtin_elementwise_fma(WH_V2(wA[i + 9 - j]), WH_TAP(2, j), p2);   // k = t+512
+                p3 = __builtin_elementwise_fma(WH_V2(wB[i + 9 - j]), WH_TAP(3, j), p3);   // k = t+768
             }
+            float2 y0 = make_float2(p0.x, p0.y), y1 = make_float2(p1.x, p1.y), y2 = make_float2(p2.x, p2.y),
+                   y3 = make_float2(p3.x, p3.y);
             fft4(y0, y1, y2, y3);  // A[k1], n1 = k/256
             y1 = cmul(y1, tw1);
             y2 = cmul(y2, tw2);
