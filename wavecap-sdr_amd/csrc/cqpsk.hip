@@ -186,9 +186,8 @@ __global__ __launch_bounds__(64) void k_cq_seq(CqArgs a) {
             double ci = DA(DM(x.x, -sn), DM(x.y, cs));
             double ph = cq_atan2(ci, cr);
             double ideal = DM(rint(DM(ph, inv_q)), q);
-            double err = DS(ph, ideal);
-            err = err > PI_D ? DS(err, 2 * PI_D) : err;
-            err = err < -PI_D ? DA(err, 2 * PI_D) : err;
+            // (the reference wraps err into [-pi, pi] here: |ph - nearest multiple of pi/4| <= pi/8, the wrap never acts)
+            const double err = DS(ph, ideal);
             s.c_freq = DA(s.c_freq, DM(a.c_ki, err));
             s.c_freq = fmin(fmax(s.c_freq, -a.c_maxf), a.c_maxf);
             s.c_phase = DA(s.c_phase, DA(DM(a.c_kp, err), s.c_freq));
@@ -271,9 +270,7 @@ __global__ __launch_bounds__(64) void k_costas(const double2 *x, size_t stride, 
             const double cr = DS(DM(xr, cs), DM(xi, -sn));     // sample * exp(-j phase)
             const double ci = DA(DM(xr, -sn), DM(xi, cs));
             const double ph = cq_atan2(ci, cr);
-            double err = DS(ph, DM(rint(DM(ph, inv_q)), q));
-            err = err > PI_D ? DS(err, 2 * PI_D) : err;
-            err = err < -PI_D ? DA(err, 2 * PI_D) : err;
+            const double err = DS(ph, DM(rint(DM(ph, inv_q)), q));   // (|err| <= pi/8: the reference's wrap never acts)
             freq = fmin(fmax(DA(freq, DM(ki, err)), -maxf), maxf);
             phase = DA(phase, DA(DM(kp, err), freq));
             while (phase > PI_D) phase = DS(phase, 2 * PI_D);
