@@ -478,6 +478,37 @@ __global__ __launch_bounds__(256) void chan_front_kernel(FmArgs a) {
     const int b_lo = blockIdx.x * per_block;
     int b_hi = b_lo + per_block;
     if (b_hi > N) b_hi = N;
+    if (a.demod == 0) {
+        // FM rows: the fused kernel's phase 1 (two samples per lane, packed arithmetic, hardware sin / cos, loads one step
+        // ahead) writing the row to memory instead of the LDS window -- window index == chunk index, this block owns
+        // [b_lo, b_hi)
+        double pb = 0.0, pf = 0.0;
+        const bool interior = b_lo >= 2 && b_hi + 128 <= N;
+#define WH_F1(CHK, F, M) fm_phase1<CHK, F, M>(a, fm, b_lo, b_hi, 0, N, c, in_base, b_lo, b_hi, lane, wave, pb, pf)
+        if (interior) {
+            if (a.fmt == 1) { if (do_mix) WH_F1(false, 1, true); else WH_F1(false, 1, false); }
+            else            { if (do_mix) WH_F1(false, 0, true); else WH_F1(false, 0, false); }
+        } else {
+            if (a.fmt == 1) { if (do_mix) WH_F1(true, 1, true); else WH_F1(true, 1, false); }
+            else            { if (do_mix) WH_F1(true, 0, true); else WH_F1(true, 0, false); }
+        }
+#undef WH_F1
+        for (int o = 32; o > 0; o >>= 1) {
+            pb += __shfl_xor(pb, o);
+            pf += __shfl_xor(pf, o);
+        }
+        if (lane == 0) {
+            red[wave] = pb;
+            red[4 + wave] = pf;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double *acc = a.acc + ((size_t)chunk * a.K + k) * 2;
+            atomicAdd(acc, red[0] + red[1] + red[2] + red[3]);
+            atomicAdd(acc + 1, red[4] + red[5] + red[6] + red[7]);
+        }
+        return;
+    }
     for (int s0 = b_lo + wave * 63; s0 < b_hi; s0 += 4 * 63) {
         int n = s0 + lane - 1;
         bool valid = (n >= 0) && (n < N);
