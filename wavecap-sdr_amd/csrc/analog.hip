@@ -173,6 +173,7 @@ struct FmArgs {
     float *fm_out;      // unfused path: [n_chunks][K][N] demodulated rows
     const float *rows_src;  // fmbank_fused_kernel as the unfused path's decimating FIR: the window comes from these rows
                             // ([n_chunks][K][N], already demodulated and filtered) instead of the discriminator
+    int skip_fm_sum;    // unfused fronts: leave acc[..][1] at zero (the rows kernel that follows owns it)
     const float *nco_c; // [K] f32(-2 pi off/fs); 0 => no mix
     const double *taps; // [ntaps]
     int fmt, N, K, n_out, ntaps, down, d0, TO, R;   // R: output tiles per workgroup (fused kernel)
@@ -505,7 +506,7 @@ __global__ __launch_bounds__(256) void chan_front_kernel(FmArgs a) {
         if (tid == 0) {
             double *acc = a.acc + ((size_t)chunk * a.K + k) * 2;
             atomicAdd(acc, red[0] + red[1] + red[2] + red[3]);
-            atomicAdd(acc + 1, red[4] + red[5] + red[6] + red[7]);
+            if (!a.skip_fm_sum) atomicAdd(acc + 1, red[4] + red[5] + red[6] + red[7]);
         }
         return;
     }
@@ -552,7 +553,7 @@ __global__ __launch_bounds__(256) void chan_front_kernel(FmArgs a) {
     if (tid == 0) {
         double *acc = a.acc + ((size_t)chunk * a.K + k) * 2;
         atomicAdd(acc, red[0] + red[1] + red[2] + red[3]);
-        atomicAdd(acc + 1, red[4] + red[5] + red[6] + red[7]);
+        if (!a.skip_fm_sum) atomicAdd(acc + 1, red[4] + red[5] + red[6] + red[7]);
     }
 }
 
@@ -860,7 +861,9 @@ __global__ __launch_bounds__(NS <= 3 ? 64 * ROWS_MAXW : 64) void chan_rows_kerne
         reinterpret_cast<int *>(st_s)[i] = reinterpret_cast<const int *>(sa.st)[i];
     __syncthreads();
     const int r0 = seg ? blockIdx.x : blockIdx.x * 64;
-    const int s0 = wave * 64;                                  // first segment of this wave (time-parallel mode)
+    // time-parallel mode: gridDim.y workgroups share a row (segments [blockIdx.y, +1) * 64 * waves)
+    const int wpg = (int)(blockDim.x >> 6), ngrp = seg ? (int)gridDim.y : 1;
+    const int s0 = ((seg ? (int)blockIdx.y : 0) * wpg + wave) * 64;   // first segment of this wave
     int nr = seg ? (N + seg - 1) / seg - s0 : n_rows - r0;     // live lanes (virtual rows)
     nr = nr < 0 ? 0 : (nr > 64 ? 64 : nr);
     double z[NS > 0 ? NS : 1][MAX_ORD - 1];
@@ -874,7 +877,7 @@ __global__ __launch_bounds__(NS <= 3 ? 64 * ROWS_MAXW : 64) void chan_rows_kerne
     // S0 != nullptr: the segments' start states were computed by iir_start_kernel (impulse-response dot product); the
     // warm-up pass (pass 0) is skipped
     if (seg && S0 != nullptr && NS > 0) {
-        const int nseg = (int)(blockDim.x >> 6) * 64;
+        const int nseg = ngrp * wpg * 64;
         const double *src = S0 + ((size_t)r0 * nseg + s0 + lane) * ep;   // compact: stage 0's states, then stage 1's, ...
         int off = 0;
 #pragma unroll
@@ -983,7 +986,9 @@ __global__ __launch_bounds__(NS <= 3 ? 64 * ROWS_MAXW : 64) void chan_rows_kerne
         if (threadIdx.x == 0) {
             double t = 0.0;
             for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red_s[w];
-            acc[(size_t)r0 * 2 + 1] = t;
+            // (two workgroups per row: the slot was left at zero for them -- FmArgs::skip_fm_sum --, and a + b == b + a)
+            if (ngrp > 1) atomicAdd(&acc[(size_t)r0 * 2 + 1], t);
+            else acc[(size_t)r0 * 2 + 1] = t;
         }
     } else if (lane < nr) {
         acc[(size_t)(r0 + lane) * 2 + 1] = ss;
@@ -1627,6 +1632,19 @@ __global__ __launch_bounds__(256) void rank_select_kernel(const float *rows, int
     }
 }
 
+// Shape of the time-parallel rows: rw waves per workgroup (64 segments each) and rg workgroups per row -- a property of the
+// bank (channel count, chunk length, chain), never of the call, so a bank's numbers do not depend on how many chunks a call
+// carries.  Chains of more than 3 stages keep one wave per row (their state alone is 20 VGPRs per stage).  Banks of one or
+// two channels whose start states come from the impulse response (no warm-up walk per segment) cut the row into 1024
+// segments, two workgroups of 8 waves: such launches are pure latency on an idle chip.
+static void rows_shape(const wh_chanbank_cfg &c, bool fir_start, int *rw_out, int *rg_out) {
+    int rw = c.n_stages > 3 ? 1 : c.n_channels <= 16 ? ROWS_MAXW : c.n_channels <= 64 ? 4 : 1;
+    while (rw > 1 && c.chunk_len < 64 * rw * 16) rw >>= 1;
+    int rg = (fir_start && rw == ROWS_MAXW && c.n_channels <= 2 && c.chunk_len >= 64 * rw * 2 * 16) ? 2 : 1;
+    *rw_out = rw;
+    *rg_out = rg;
+}
+
 struct wh_chanbank {
     wh_chanbank_cfg cfg;
     float *d_nco = nullptr;
@@ -1869,9 +1887,9 @@ extern "C" int wh_chanbank_run_wire(wh_chanbank *b, const void *d_in, size_t n_c
             (void)hipFree(b->d_S0);
             b->d_S0 = nullptr;
             // (segments per row: the warm-up form's wave count is a property of the bank, see below)
-            int rw = c.n_stages > 3 ? 1 : c.n_channels <= 16 ? ROWS_MAXW : c.n_channels <= 64 ? 4 : 1;
-            while (rw > 1 && c.chunk_len < 64 * rw * 16) rw >>= 1;
-            WH_HIP(hipMalloc(&b->d_S0, rows * (size_t)(64 * rw) * b->start_ep * sizeof(double)));
+            int rw, rg;
+            rows_shape(c, b->d_G != nullptr, &rw, &rg);
+            WH_HIP(hipMalloc(&b->d_S0, rows * (size_t)(64 * rw * rg) * b->start_ep * sizeof(double)));
         }
         if (b->nr) {
             (void)hipFree(b->d_nr_mag); (void)hipFree(b->d_nr_sel); (void)hipFree(b->d_nr_stft);
@@ -1890,6 +1908,7 @@ extern "C" int wh_chanbank_run_wire(wh_chanbank *b, const void *d_in, size_t n_c
     a.acc = b->d_acc;
     a.fm_out = (resample || b->nr) ? b->d_fm : d_audio;   // no resampling, no length change: rows are the audio
     a.rows_src = nullptr;
+    a.skip_fm_sum = (!b->fused && (c.n_stages > 0 || c.agc)) ? 1 : 0;
     a.nco_c = b->d_nco;
     a.taps = b->d_taps;
     a.fmt = c.input_format;
@@ -1930,22 +1949,19 @@ extern "C" int wh_chanbank_run_wire(wh_chanbank *b, const void *d_in, size_t n_c
             g.att_b0 = c.agc_att_b0; g.att_a1 = c.agc_att_a1;
             g.rel_b0 = c.agc_rel_b0; g.rel_a1 = c.agc_rel_a1;
             // time-parallel mode when it at least halves the sequential depth (see chan_rows_kernel)
-            int seg = 0, rw = 1;
+            int seg = 0, rw = 1, rg = 1;
             if (!c.agc && c.iir_warmup > 0 && c.n_stages > 0) {
                 const int sg = (c.chunk_len + 63) / 64;
                 if (sg + c.iir_warmup <= c.chunk_len / 2) {
-                    // waves per row: a property of the bank (channel count, chunk length), never of the call
-                    // (chains of more than 3 stages keep one wave per row: their state alone is 20 VGPRs per stage)
-                    rw = c.n_stages > 3 ? 1 : c.n_channels <= 16 ? ROWS_MAXW : c.n_channels <= 64 ? 4 : 1;
-                    while (rw > 1 && c.chunk_len < 64 * rw * 16) rw >>= 1;
-                    seg = (c.chunk_len + 64 * rw - 1) / (64 * rw);
+                    rows_shape(c, b->d_G != nullptr, &rw, &rg);
+                    seg = (c.chunk_len + 64 * rw * rg - 1) / (64 * rw * rg);
                 }
             }
             const double *S0 = nullptr;
             if (seg && b->d_G) {   // start states of all segments, chip-wide (iir_start_kernel)
-                const dim3 sg2((unsigned)rows, (unsigned)((64 * rw + START_SEGS - 1) / START_SEGS));
+                const dim3 sg2((unsigned)rows, (unsigned)((64 * rw * rg + START_SEGS - 1) / START_SEGS));
 #define WH_START(EP_)                                                                                                     \
-    hipLaunchKernelGGL(iir_start_kernel<EP_>, sg2, dim3(256), 0, st, a.fm_out, c.chunk_len, seg, c.iir_warmup, 64 * rw,   \
+    hipLaunchKernelGGL(iir_start_kernel<EP_>, sg2, dim3(256), 0, st, a.fm_out, c.chunk_len, seg, c.iir_warmup, 64 * rw * rg, \
                        b->d_G, b->d_S0)
                 switch (b->start_ep) {
                     case 2: WH_START(2); break;
@@ -1967,14 +1983,14 @@ extern "C" int wh_chanbank_run_wire(wh_chanbank *b, const void *d_in, size_t n_c
                                    b->stages, c.n_stages, g, b->scan_seg, b->d_pow);
                 WH_LAUNCH_CHECK();
             } else {
-            const dim3 rg(seg ? (unsigned)rows : (unsigned)((rows + 63) / 64));
+            const dim3 rgrid(seg ? (unsigned)rows : (unsigned)((rows + 63) / 64), (unsigned)(seg ? rg : 1));
             const size_t tile_bytes = (size_t)rw * ROWS_CH * 65 * sizeof(float);
 #define WH_ROWS(NS_)                                                                                                      \
     do {                                                                                                                  \
         if (tile_bytes > 64 * 1024)                                                                                       \
             WH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chan_rows_kernel<NS_>),                             \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_bytes));                     \
-        hipLaunchKernelGGL(chan_rows_kernel<NS_>, rg, dim3(64 * rw), tile_bytes, st, a.fm_out, b->d_acc, (int)rows,       \
+        hipLaunchKernelGGL(chan_rows_kernel<NS_>, rgrid, dim3(64 * rw), tile_bytes, st, a.fm_out, b->d_acc, (int)rows,    \
                            c.chunk_len, b->stages, g, seg, c.iir_warmup, S0, b->start_ep);                                \
     } while (0)
             switch (c.n_stages) {
@@ -2063,7 +2079,7 @@ extern "C" int wh_channel_signal_metrics(const void *d_in, int input_format, siz
     WH_HIP(hipMemcpyAsync(d_nco, nco.data(), K * sizeof(float), hipMemcpyHostToDevice, st));
     WH_HIP(hipMemsetAsync(d_acc, 0, (size_t)K * 2 * sizeof(double), st));
     FmArgs a;
-    a.in = d_in; a.audio = nullptr; a.acc = d_acc; a.fm_out = d_rows; a.rows_src = nullptr; a.nco_c = d_nco; a.taps = nullptr;
+    a.in = d_in; a.audio = nullptr; a.acc = d_acc; a.fm_out = d_rows; a.rows_src = nullptr; a.skip_fm_sum = 0; a.nco_c = d_nco; a.taps = nullptr;
     a.fmt = input_format; a.N = (int)n; a.K = K; a.n_out = 0; a.ntaps = 0; a.down = 1; a.d0 = 0; a.TO = 1; a.R = 1;
     a.scale = 0.f; a.demod = 1; a.bfo_c = 0.0; a.fs_d = (double)sample_rate; a.pll_alpha = a.pll_beta = 0.0;
     const int per_block = 4 * 63 * 16;
