@@ -284,13 +284,20 @@ int wh_scan_measure(const float *d_iq, size_t n, int sample_rate, const int *h_o
  * `iq_stride` complex) and appends its dibits / soft symbols to d_dibits[ch][cap] /
  * d_soft[ch][cap]; d_counts[ch] = symbols produced by this call.  State (filter zi,
  * 65536-sample phase buffer, sample_point, equaliser, sync rings) is carried on the
- * device between calls; reset() == C4FMDemodulator.reset() (c4fm.py:2505-2521).      */
+ * device between calls; reset() == C4FMDemodulator.reset() (c4fm.py:2505-2521).
+ * Call size: ONE run() == ONE demodulate(iq) of the reference, whatever n is (the reference's block processing is
+ * not invariant to where a stream is cut: the whole call's symbols are extracted with the call-start equaliser, the
+ * sync search runs on the 65 536-sample phase buffer as it stands after the call, symbols that were shifted out of
+ * it carry index -1, c4fm.py:704-728, 2621-2770 -- production calls are 72 000-75 000 samples,
+ * trunking/system.py:1548-1549).  n <= the bank's max_samples_per_call <= 2^24; reserve() grows that bound (it
+ * allocates and synchronises -- not for the hot path), out_cap >= n / 4 + 2.                                   */
 typedef struct wh_c4fm_bank wh_c4fm_bank;
 int wh_c4fm_bank_create(wh_c4fm_bank **out, int n_channels, double samples_per_symbol,
                         const float *h_lpf, int n_lpf, const float *h_rrc, int n_rrc,
                         const float *h_interp_taps /* float32[129][8] */, int max_samples_per_call);
 int wh_c4fm_bank_run(wh_c4fm_bank *b, const float *d_iq, size_t n, size_t iq_stride,
                      uint8_t *d_dibits, float *d_soft, size_t out_cap, int32_t *d_counts, void *stream);
+int wh_c4fm_bank_reserve(wh_c4fm_bank *b, size_t max_samples_per_call, void *stream);
 int wh_c4fm_bank_reset(wh_c4fm_bank *b, void *stream);
 void wh_c4fm_bank_destroy(wh_c4fm_bank *b);
 
@@ -330,13 +337,18 @@ void wh_bch_destroy(wh_bch *b);
  * Costas loop (c_kp, c_ki, c_maxf; cqpsk.py:94-119), Mueller-Muller timing (t_kp, t_ki;
  * symbol_timing.py:238-270), pi/4-DQPSK differential decode.  All float64 like the reference.
  * run(): d_iq complex64 [C][iq_stride] -> d_dibits uint8 [C][cap]; d_symbols (optional, may be
- * NULL) complex128 [C][cap]; d_counts int32 [C].  State carried on the device.              */
+ * NULL) complex128 [C][cap]; d_counts int32 [C].  State carried on the device.
+ * ONE run() == ONE demodulate(iq) of the reference for any n <= max_samples_per_call (the reference re-seeds the
+ * matched filter with zi = state * iq[0] on every call, cqpsk.py:283-285, so a stream cut differently gives different
+ * dibits); reserve() grows max_samples_per_call (allocates and synchronises).  samples_per_symbol >= 2;
+ * cap >= n / (samples_per_symbol / 2) + 2 (the timing loop's period never drops below sps / 2).              */
 typedef struct wh_cqpsk_bank wh_cqpsk_bank;
 int wh_cqpsk_bank_create(wh_cqpsk_bank **out, int n_channels, double samples_per_symbol, const float *h_rrc,
                          int ntaps, const double *h_zi, double c_kp, double c_ki, double c_maxf, double t_kp,
                          double t_ki, int max_samples_per_call);
 int wh_cqpsk_bank_run(wh_cqpsk_bank *b, const float *d_iq, size_t n, size_t iq_stride, uint8_t *d_dibits,
                       double *d_symbols, size_t cap, int32_t *d_counts, void *stream);
+int wh_cqpsk_bank_reserve(wh_cqpsk_bank *b, size_t max_samples_per_call, void *stream);
 int wh_cqpsk_bank_reset(wh_cqpsk_bank *b, void *stream);
 void wh_cqpsk_bank_destroy(wh_cqpsk_bank *b);
 

@@ -640,6 +640,89 @@ def gen_chain4():
     save("chain4", **out)
 
 
+def gen_c4fm_big():
+    """A9-A11 at the CALLER'S call sizes: the control-channel monitor hands demodulate() max(20 000, 1.5 fs) samples
+    (trunking/system.py:1548-1549 -> control_channel.py:230-231), cli.py:755 a whole recording.  The reference's block
+    processing is not cut-invariant (symbol extraction of the whole call uses the call-start equaliser; sync search runs
+    on the FINAL 65 536-sample phase buffer, symbols shifted out of it get index -1, c4fm.py:704-728), so these pin the
+    one-call results: single 72 000 / 75 000-sample calls, three consecutive 72 000-sample calls (carried state, a buffer
+    shift inside a call), one 200 000-sample call (>= 2 shifts: early symbols index -1), one 150 000-sample call at sps 4."""
+    out = {}
+    cases = [
+        # (fs, seed, snr_db, foff_hz, [call lengths])
+        (48000, 1100, 20.0, 140.0, [72000]),
+        (50000, 1101, 18.0, -220.0, [75000]),
+        (48000, 1102, 22.0, 90.0, [72000, 72000, 72000]),
+        (48000, 1103, 20.0, -60.0, [200000]),
+        (19200, 1104, 16.0, 40.0, [150000, 28800]),
+        (48000, 1105, 25.0, 310.0, [4800, 100000, 333, 72000]),
+    ]
+    for ci, (fs, seed, snr, foff, calls) in enumerate(cases):
+        n = sum(calls)
+        iq, _ = S.c4fm_iq(n, fs, seed, snr_db=snr, freq_offset_hz=foff)
+        d = rc4.C4FMDemodulator(sample_rate=fs)
+        dib, soft, counts, pos = [], [], [], 0
+        for m in calls:
+            a, b = d.demodulate(iq[pos:pos + m])
+            pos += m
+            dib.append(a); soft.append(b); counts.append(len(a))
+        out[f"c{ci}_args"] = np.array([fs, seed, int(round(snr * 10)), int(round(foff * 10))], dtype=np.int64)
+        out[f"c{ci}_calls"] = np.array(calls, dtype=np.int64)
+        out[f"c{ci}_sha"] = np.array(S.sha256(iq))
+        out[f"c{ci}_dibits"] = np.concatenate(dib).astype(np.uint8)
+        out[f"c{ci}_soft"] = np.concatenate(soft).astype(np.float32)
+        out[f"c{ci}_counts"] = np.array(counts, dtype=np.int32)
+        out[f"c{ci}_state"] = np.array([d._sync_count, int(d._fine_sync), d._equalizer.pll, d._equalizer.gain,
+                                        float(d._sample_point), d._buffer_pointer, d._symbols_since_sync])
+        print(f"  c4fm_big case {ci}: syms={sum(counts)} syncs={d._sync_count} fine={d._fine_sync} "
+              f"bp={d._buffer_pointer} pll={d._equalizer.pll:.4f} gain={d._equalizer.gain:.4f}")
+    out["n_cases"] = np.array(len(cases))
+    save("c4fm_big", **out)
+
+
+def gen_cqpsk_big():
+    """A12 Phase-2 chain at large / odd call shapes: demodulate() re-seeds the matched filter with zi = state * iq[0]
+    on every call (cqpsk.py:283-285), so results depend on where calls are cut: one 140 000-sample call; and
+    samples_per_symbol = 5 and 5.2083 (sps / 2 not an integer), CQPSKDemodulator and MuellerMullerTED."""
+    from wavecapsdr.dsp.p25.cqpsk import CostasLoop, CQPSKDemodulator as RefCQPSK
+    from wavecapsdr.dsp.p25.symbol_timing import MuellerMullerTED
+
+    out = {}
+    cases = [(48000, 12000, 1510, 24.0, 35.0, [140000]), (60000, 12000, 1511, 22.0, -50.0, [2500, 9000, 21]),
+             (62500, 12000, 1512, 26.0, 20.0, [2500, 7000])]
+    for ci, (fs, sr, seed, snr, foff, calls) in enumerate(cases):
+        n = sum(calls)
+        iq, _ = S.dqpsk_iq(n, fs, seed, symbol_rate=sr, snr_db=snr, freq_offset_hz=foff)
+        d = RefCQPSK(sample_rate=fs, symbol_rate=sr)
+        dib, pos = [], 0
+        for m in calls:
+            dib.append(d.demodulate(iq[pos:pos + m]))
+            pos += m
+        out[f"c{ci}_args"] = np.array([fs, sr, seed, int(snr * 10), int(foff * 10)], dtype=np.int64)
+        out[f"c{ci}_calls"] = np.array(calls, dtype=np.int64)
+        out[f"c{ci}_sha"] = np.array(S.sha256(iq))
+        out[f"c{ci}_dibits"] = np.concatenate(dib).astype(np.uint8)
+        out[f"c{ci}_counts"] = np.array([len(x) for x in dib], dtype=np.int64)
+        out[f"c{ci}_state"] = np.array([d._carrier_loop._phase, d._carrier_loop._freq, d._timing_recovery._phase,
+                                        d._timing_recovery._integrator])
+        print(f"  cqpsk_big case {ci}: dibits={sum(len(x) for x in dib)}")
+    out["n_cases"] = np.array(len(cases))
+    # MuellerMullerTED standalone at sps 5 and 5.2083 on a Costas-corrected carrier, two calls each
+    iq, _ = S.dqpsk_iq(6000, 60000, 1513, symbol_rate=12000, snr_db=22.0, freq_offset_hz=30.0)
+    x = CostasLoop().process_block(iq.astype(np.complex128))
+    out["mm_sha"] = np.array(S.sha256(iq))
+    out["mm_in"] = x
+    for tag, sps in (("s5", 5.0), ("s52", 62500 / 12000)):
+        mm = MuellerMullerTED(sps)
+        a, b = mm.process_block(x[:2500]), mm.process_block(x[2500:])
+        out[f"mm_{tag}_sps"] = np.array([sps])
+        out[f"mm_{tag}_counts"] = np.array([len(a[0]), len(b[0])], dtype=np.int64)
+        out[f"mm_{tag}_sym"] = np.concatenate([a[0], b[0]])
+        out[f"mm_{tag}_dec"] = np.concatenate([a[1], b[1]])
+        out[f"mm_{tag}_err"] = np.concatenate([a[2], b[2]])
+    save("cqpsk_big", **out)
+
+
 def gen_blanker():
     """A14: noise_blanker (dsp/filters.py:267-343) on float32 audio with impulses; even and odd lengths."""
     from wavecapsdr.dsp.filters import noise_blanker
@@ -809,7 +892,7 @@ def gen_lsm():
     save("lsm", **out)
 
 
-ALL = dict(status=gen_status, cqpsk_parts=gen_cqpsk_parts, chain4=gen_chain4, blanker=gen_blanker, nid=gen_nid, classifier=gen_classifier, recorder=gen_recorder, nr=gen_nr, sam=gen_sam, rawdig=gen_rawdig, lsm=gen_lsm, framer=gen_framer, cqpsk=gen_cqpsk, trunk=gen_trunk, a1=gen_a1, a2=gen_a2, a3=gen_a3, a6=gen_a6, chain=gen_chain, a7=gen_a7, a8=gen_a8, c4fm=gen_c4fm)
+ALL = dict(c4fm_big=gen_c4fm_big, cqpsk_big=gen_cqpsk_big, status=gen_status, cqpsk_parts=gen_cqpsk_parts, chain4=gen_chain4, blanker=gen_blanker, nid=gen_nid, classifier=gen_classifier, recorder=gen_recorder, nr=gen_nr, sam=gen_sam, rawdig=gen_rawdig, lsm=gen_lsm, framer=gen_framer, cqpsk=gen_cqpsk, trunk=gen_trunk, a1=gen_a1, a2=gen_a2, a3=gen_a3, a6=gen_a6, chain=gen_chain, a7=gen_a7, a8=gen_a8, c4fm=gen_c4fm)
 
 if __name__ == "__main__":
     import logging

@@ -78,3 +78,35 @@ def test_c4fm_oracle_matches_reference_on_the_frame_head_carrier(golden, atan_mo
         assert np.array_equal(np.array(counts, dtype=np.int32), g[f"c{ci}_counts"]), ci
         assert np.array_equal(np.concatenate(dib), g[f"c{ci}_dibits"]), ci
         assert peak_rel_err(np.concatenate(soft), g[f"c{ci}_soft"]) <= 1e-5, ci
+
+
+def big_case(g, ci):
+    fs, seed, snr10, foff10 = (int(v) for v in g[f"c{ci}_args"])
+    calls = [int(v) for v in g[f"c{ci}_calls"]]
+    iq, _ = S.c4fm_iq(sum(calls), fs, seed, snr_db=snr10 / 10.0, freq_offset_hz=foff10 / 10.0)
+    assert S.sha256(iq) == str(g[f"c{ci}_sha"])
+    return fs, calls, iq
+
+
+@pytest.mark.parametrize("atan_mode", [0, 1])
+def test_c4fm_oracle_matches_reference_at_production_call_sizes(golden, atan_mode):
+    """`c4fm_big`: demodulate() at the callers' sizes -- single 72 000 / 75 000-sample calls (trunking/system.py:1548-1549),
+    three consecutive ones, one 200 000-sample call (two phase-buffer shifts, early symbols fall out of the buffer:
+    index -1, c4fm.py:716-728), 150 000 samples at sps = 4, mixed small / large calls.  The reference is not
+    cut-invariant, so every call is made exactly as the golden's was."""
+    g = golden("c4fm_big")
+    for ci in range(int(g["n_cases"])):
+        fs, calls, iq = big_case(g, ci)
+        d = C4FMDemodulatorRef(sample_rate=fs, atan_mode=atan_mode)
+        dib, soft, counts, pos = [], [], [], 0
+        for m in calls:
+            a, b = d.demodulate(iq[pos:pos + m])
+            pos += m
+            dib.append(a); soft.append(b); counts.append(len(a))
+        assert np.array_equal(np.array(counts, dtype=np.int32), g[f"c{ci}_counts"]), ci
+        mism = np.flatnonzero(np.concatenate(dib) != g[f"c{ci}_dibits"])
+        assert mism.size == 0, f"case {ci}: {mism.size} dibit mismatches, first at {mism[:5]}"
+        assert peak_rel_err(np.concatenate(soft), g[f"c{ci}_soft"]) <= 1e-5, ci
+        st, ref = d.state(), g[f"c{ci}_state"]
+        assert st["sync_count"] == int(ref[0]) and st["fine_sync"] == bool(ref[1]) and st["buffer_pointer"] == int(ref[5])
+        assert abs(st["pll"] - ref[2]) <= 1e-5 and abs(st["gain"] - ref[3]) <= 1e-6 and abs(st["sample_point"] - ref[4]) <= 1e-6

@@ -72,3 +72,41 @@ def test_costas_and_mueller_muller_oracle_match_reference(golden):
     assert np.max(np.abs(np.concatenate([a[0], b[0]]) - g["mm_sym"])) <= 1e-12
     assert np.array_equal(np.concatenate([a[1], b[1]]), g["mm_dec"])
     assert np.max(np.abs(np.concatenate([a[2], b[2]]) - g["mm_err"])) <= 1e-12
+
+
+def cqpsk_big_case(g, ci):
+    fs, sr, seed, snr10, foff10 = (int(v) for v in g[f"c{ci}_args"])
+    calls = [int(v) for v in g[f"c{ci}_calls"]]
+    iq, _ = S.dqpsk_iq(sum(calls), fs, seed, symbol_rate=sr, snr_db=snr10 / 10.0, freq_offset_hz=foff10 / 10.0)
+    assert S.sha256(iq) == str(g[f"c{ci}_sha"])
+    return fs, sr, iq, calls
+
+
+def test_cqpsk_oracle_matches_reference_big_call_and_odd_sps(golden):
+    """`cqpsk_big`: one 140 000-sample call (the chain re-seeds its matched filter with zi * iq[0] per call,
+    cqpsk.py:283-285: results depend on the cut), samples_per_symbol 5 and 5.2083 (sps / 2 not an integer)."""
+    g = golden("cqpsk_big")
+    for ci in range(int(g["n_cases"])):
+        fs, sr, iq, calls = cqpsk_big_case(g, ci)
+        d = CQPSKDemodulatorRef(sample_rate=fs, symbol_rate=sr)
+        dib, pos = [], 0
+        for m in calls:
+            dib.append(d.demodulate(iq[pos:pos + m]))
+            pos += m
+        assert [len(x) for x in dib] == [int(v) for v in g[f"c{ci}_counts"]], ci
+        mism = np.flatnonzero(np.concatenate(dib) != g[f"c{ci}_dibits"])
+        assert mism.size == 0, f"case {ci}: {mism.size} dibit mismatches, first {mism[:5]}"
+
+
+def test_mueller_muller_oracle_odd_sps(golden):
+    from oracle import ref_np as O
+
+    g = golden("cqpsk_big")
+    x = g["mm_in"]
+    for tag in ("s5", "s52"):
+        mm = O.MuellerMullerTED(float(g[f"mm_{tag}_sps"][0]))
+        a, b = mm.process_block(x[:2500]), mm.process_block(x[2500:])
+        assert [len(a[0]), len(b[0])] == [int(v) for v in g[f"mm_{tag}_counts"]]
+        assert np.max(np.abs(np.concatenate([a[0], b[0]]) - g[f"mm_{tag}_sym"])) <= 1e-12
+        assert np.array_equal(np.concatenate([a[1], b[1]]), g[f"mm_{tag}_dec"])
+        assert np.max(np.abs(np.concatenate([a[2], b[2]]) - g[f"mm_{tag}_err"])) <= 1e-12

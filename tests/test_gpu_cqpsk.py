@@ -99,3 +99,33 @@ def test_costas_loop_and_mueller_muller_ted_standalone(golden):
     s0 = wavehip.MuellerMullerTED(fs / sr).process_block(cb[0].cpu().numpy())
     assert int(nb[0]) == len(s0[0]) and np.max(np.abs(sb[0, :len(s0[0])].cpu().numpy() - s0[0])) <= 1e-12
     assert wavehip.CostasLoop().process_block(np.zeros(0)).size == 0 and len(wavehip.MuellerMullerTED(4.0).process_block([])[0]) == 0
+
+
+def test_cqpsk_big_call_and_odd_samples_per_symbol(golden):
+    """`cqpsk_big` (from the reference): ONE 140 000-sample demodulate() call (never split: the chain re-seeds its matched
+    filter with zi * iq[0] per call, cqpsk.py:283-285) and samples_per_symbol = 5 / 5.2083, where sps / 2 is not an
+    integer (the capacity bound is computed in floating point on both sides of the ABI)."""
+    import wavehip
+    from test_cqpsk_oracle import cqpsk_big_case
+
+    g = golden("cqpsk_big")
+    for ci in range(int(g["n_cases"])):
+        fs, sr, iq, calls = cqpsk_big_case(g, ci)
+        d = wavehip.CQPSKDemodulator(sample_rate=fs, symbol_rate=sr)
+        dib, pos = [], 0
+        for m in calls:
+            dib.append(d.demodulate(iq[pos:pos + m]))
+            pos += m
+        assert [len(x) for x in dib] == [int(v) for v in g[f"c{ci}_counts"]], ci
+        mism = np.flatnonzero(np.concatenate(dib) != g[f"c{ci}_dibits"])
+        assert mism.size == 0, f"case {ci}: {mism.size} dibit mismatches, first {mism[:5]}"
+    x = g["mm_in"]
+    for tag in ("s5", "s52"):
+        mm = wavehip.MuellerMullerTED(float(g[f"mm_{tag}_sps"][0]))
+        a, b = mm.process_block(x[:2500]), mm.process_block(x[2500:])
+        assert [len(a[0]), len(b[0])] == [int(v) for v in g[f"mm_{tag}_counts"]]
+        assert np.max(np.abs(np.concatenate([a[0], b[0]]) - g[f"mm_{tag}_sym"])) <= 1e-9
+        assert np.max(np.abs(np.concatenate([a[1], b[1]]) - g[f"mm_{tag}_dec"])) <= 1e-15
+        assert np.max(np.abs(np.concatenate([a[2], b[2]]) - g[f"mm_{tag}_err"])) <= 1e-9
+    with pytest.raises(Exception):
+        wavehip.MuellerMullerTED(1.5)      # sps < 2: refused at create (was an integer division by zero on the host)

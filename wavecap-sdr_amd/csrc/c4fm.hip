@@ -45,7 +45,7 @@ struct C4Args {
     size_t iq_stride;
     int n, n_max, C;
     double sps, lagging_offset, max_fine_adj;
-    int nl, nr, overlap, interp_offset, fm_row, ns_max;
+    int nl, nr, overlap, interp_offset, fm_row, ns_max, ns_call;
     const float *lpf, *rrc, *taps;  // taps [129][8]
     float2 *xh;          // [C][nl-1]      input history
     double2 *y;          // [C][nr-1 + n_max]  LPF output with history prefix
@@ -55,7 +55,8 @@ struct C4Args {
     ChanState *st;       // [C]
     int *sym_x;          // [C][ns_max] sample index of each symbol
     double *sym_sp;      // [C][ns_max] sample_point at the symbol
-    int *sym_idx;        // [C][ns_max] buffer index
+    int *sym_idx;        // [C][ns_max] buffer index in the FINAL buffer of the call (-1: shifted out)
+    float *ss;           // [C][2 (24 + ns_max)] detector streams of calls too long for LDS (GSTREAM form)
     uint8_t *dibits;     // [C][out_cap]
     float *soft;         // [C][out_cap]
     size_t out_cap;
@@ -250,11 +251,19 @@ __device__ float timing_score(const ScoreCtx &c, double offset) {
     return score;
 }
 
+// GSTREAM: the two detector streams live in the workspace instead of LDS (calls of more than ~8 000 symbols)
+template <bool GSTREAM>
 __global__ __launch_bounds__(64) void k_seq(C4Args a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int c = blockIdx.x, lane = threadIdx.x;
-    float *SS = sm;                         // [24 + ns_max] primary detector stream (history first)
-    float *LL = sm + 24 + a.ns_max;         // [24 + ns_max] lagging detector stream
+    float *SS, *LL;                         // [24 + ns] primary / lagging detector streams (history first)
+    if constexpr (GSTREAM) {
+        SS = a.ss + (size_t)c * 2 * (24 + a.ns_max);
+        LL = SS + 24 + a.ns_max;
+    } else {
+        SS = sm;
+        LL = sm + 24 + a.ns_call;
+    }
     ChanScalars st = a.st[c].s;
     float *buf = a.buffer + (size_t)c * BUF_LEN;
     const float *ph = a.phases + (size_t)c * a.n_max;
@@ -272,7 +281,7 @@ __global__ __launch_bounds__(64) void k_seq(C4Args a) {
     {
         double sp = st.sample_point;
         long long x = -1;
-        const int cap = (int)(a.out_cap < (size_t)a.ns_max ? a.out_cap : (size_t)a.ns_max);
+        const int cap = (int)(a.out_cap < (size_t)a.ns_call ? a.out_cap : (size_t)a.ns_call);
         while (true) {
             double d = floor(sp - 1.0) + 1.0;      // decrements until sp - d < 1.0 (at least one)
             if (!(d >= 1.0)) d = 1.0;
@@ -294,32 +303,45 @@ __global__ __launch_bounds__(64) void k_seq(C4Args a) {
         }
         st.sample_point = sp;
     }
-    // ---- phase buffer management (c4fm.py:705-728): at most one shift per call (n < 32768) ---
+    // ---- phase buffer management (c4fm.py:705-728) in closed form --------------------------------
+    // The reference appends sample by sample and, whenever the write pointer reaches the end, moves the upper half
+    // down and zeroes it; the sync search below runs on the buffer as it stands AFTER the whole call.  With ptr0 the
+    // pointer at call start the first shift happens at sample x_first = 65534 - ptr0, the next ones every 32768
+    // samples: S shifts in all, sample x ends at position base + x with base = ptr0 + 1 - 32768 S (negative:
+    // shifted out), everything beyond the final pointer is zero, and what earlier calls left moves down by 32768 S.
     const int ptr0 = st.buffer_pointer;
-    const int x_shift = (BUF_LEN - 2) - ptr0;          // first sample index whose pointer hits the end
-    const bool shift = x_shift < n;
-    if (shift) {
+    const long long x_first = (long long)(BUF_LEN - 2) - ptr0;
+    const int S = x_first < n ? 1 + (int)(((long long)n - 1 - x_first) / HALF_BUF) : 0;
+    const long long base = (long long)ptr0 + 1 - (long long)S * HALF_BUF;
+    const float prev0 = buf[ptr0];   // the sample before this call's first: x1 of a symbol at x = 0
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    if (S == 1) {
         for (int i = lane; i < HALF_BUF; i += 64) {
             buf[i] = buf[i + HALF_BUF];
             buf[i + HALF_BUF] = 0.f;
         }
+    } else if (S >= 2) {             // nothing of the earlier calls is left (base <= 0)
+        for (int i = lane; i < BUF_LEN; i += 64) buf[i] = 0.f;
     }
-    const int base = ptr0 + 1 - (shift ? HALF_BUF : 0);  // final buffer position of sample 0
     __threadfence_block();
-    for (int x = lane; x < n; x += 64) buf[base + x] = ph[x];
-    st.buffer_pointer = base + n - 1;
+    for (long long x = (base < 0 ? -base : 0) + lane; x < n; x += 64) buf[base + x] = ph[x];
+    st.buffer_pointer = (int)(base + n - 1);
     __threadfence_block();
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
 
     // ---- symbol extraction, parallel over symbols (c4fm.py:731-771) ---------------------------
+    // x1 / x2 are the previous and the current phase sample at the time of the symbol, i.e. ph[x - 1], ph[x];
+    // the recorded index is the symbol's place in the final buffer, -1 once a shift moved it out (c4fm.py:722-728)
     {
         const float pll32 = (float)st.pll, gain32 = (float)st.gain;
         for (int k = lane; k < count; k += 64) {
-            int idx = base + sym_x[k];
+            const int x = sym_x[k];
+            const long long fidx = base + x;
             double spk = sym_sp[k];
             double mu = __dsub_rn(1.0, spk);
-            float x1 = buf[idx - 1], x2 = buf[idx];
+            float x1 = x > 0 ? ph[x - 1] : prev0, x2 = ph[x];
             int d;
             float sn;
             if (mu < 0.0 || mu > 1.0 || !st.sp_np64) {
@@ -335,7 +357,7 @@ __global__ __launch_bounds__(64) void k_seq(C4Args a) {
             }
             dib[k] = (uint8_t)d;
             soft[k] = sn;
-            sym_idx[k] = idx;
+            sym_idx[k] = fidx < 0 ? -1 : (int)fidx;
             SS[24 + k] = sn;
         }
         if (lane < 24) {
@@ -343,6 +365,7 @@ __global__ __launch_bounds__(64) void k_seq(C4Args a) {
             LL[lane] = a.st[c].lag_hist[lane];
         }
     }
+    if constexpr (GSTREAM) __threadfence_block();
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
 
@@ -388,6 +411,7 @@ __global__ __launch_bounds__(64) void k_seq(C4Args a) {
             unsigned long long pm = __ballot(pushes);
             int my_pos = n_lag + __popcll(pm & ((1ULL << lane) - 1ULL));  // stream position of my push
             if (pushes) LL[24 + my_pos] = sln;
+            if constexpr (GSTREAM) __threadfence_block();
             __builtin_amdgcn_s_waitcnt(0);
             __builtin_amdgcn_wave_barrier();
             if (pushes) {
@@ -399,8 +423,12 @@ __global__ __launch_bounds__(64) void k_seq(C4Args a) {
         }
         const bool use_lag = coarse && L > P && L >= 100.0f;
         const float score = use_lag ? L : P;
-        const bool trig = in && score >= 100.0f;
-        const bool lose = in && (st.symbols_since_sync + lane + 1 > 3600);
+        // a detection on a symbol whose samples have left the buffer is skipped with `continue` (c4fm.py:2663-2665):
+        // no optimiser run and no fine-sync-loss check for that symbol either
+        const bool hit = in && score >= 100.0f;
+        const bool gone = in && sym_idx[k] < 0;
+        const bool trig = hit && !gone;
+        const bool lose = in && !(hit && gone) && (st.symbols_since_sync + lane + 1 > 3600);
         unsigned long long em = __ballot(trig || lose);
         if (em == 0ULL) {  // no event in this block: commit and advance
             int nin = count - kb < 64 ? count - kb : 64;
@@ -549,6 +577,7 @@ __global__ __launch_bounds__(64) void k_seq(C4Args a) {
                     soft[ke + 1 + i] = sn;
                     SS[24 + ke + 1 + i] = sn;
                 }
+                if constexpr (GSTREAM) __threadfence_block();
                 __builtin_amdgcn_s_waitcnt(0);
                 __builtin_amdgcn_wave_barrier();
             }
@@ -591,18 +620,70 @@ __global__ void k_reset(ChanState *st, int C, double sps) {
 
 }  // namespace
 
+constexpr int C4_N_CAP = 1 << 24;          // samples per call and channel the workspace may be sized for
+constexpr size_t C4_LDS_STREAMS = 64 * 1024;  // detector streams beyond this many bytes go to the workspace
+
 struct wh_c4fm_bank {
-    int C, n_max, nl, nr, overlap, interp_offset, fm_row, ns_max;
+    int C, n_max = 0, nl, nr, overlap, interp_offset, fm_row, ns_max = 0;
     double sps;
     float *d_lpf = nullptr, *d_rrc = nullptr, *d_taps = nullptr;
     float2 *d_xh = nullptr;
     double2 *d_y = nullptr;
     float2 *d_z = nullptr;
-    float *d_phases = nullptr, *d_buffer = nullptr;
+    float *d_phases = nullptr, *d_buffer = nullptr, *d_ss = nullptr;
     ChanState *d_st = nullptr;
     int *d_sym_x = nullptr, *d_sym_idx = nullptr;
     double *d_sym_sp = nullptr;
 };
+
+static int c4_ns(double sps, int n) { return (int)((double)n / sps) + 16; }
+static size_t c4_stream_bytes(int ns) { return (size_t)2 * (24 + ns) * sizeof(float); }
+
+// (re)size the per-call workspaces for calls of up to n_max samples; the FIR histories at the head of every channel's
+// y / z row are carried over
+static int c4fm_resize(wh_c4fm_bank *b, int n_max, hipStream_t st) {
+    const int C = b->C, Hy = b->nr - 1, Hz = b->overlap;
+    const int ns_max = c4_ns(b->sps, n_max);
+    double2 *y = nullptr;
+    float2 *z = nullptr;
+    float *ph = nullptr, *ss = nullptr;
+    int *sx = nullptr, *si = nullptr;
+    double *sp = nullptr;
+    auto drop = [&]() {
+        (void)hipFree(y); (void)hipFree(z); (void)hipFree(ph); (void)hipFree(ss); (void)hipFree(sx); (void)hipFree(si);
+        (void)hipFree(sp);
+    };
+#define C4_TRY(x)                                                                                  \
+    do {                                                                                           \
+        hipError_t e_ = (x);                                                                       \
+        if (e_ != hipSuccess) { drop(); return set_err(WH_E_HIP, "c4fm workspace: %s", hipGetErrorString(e_)); }       \
+    } while (0)
+    C4_TRY(hipMalloc(&y, (size_t)C * (Hy + n_max) * sizeof(double2)));
+    C4_TRY(hipMalloc(&z, (size_t)C * (Hz + n_max) * sizeof(float2)));
+    C4_TRY(hipMalloc(&ph, (size_t)C * n_max * sizeof(float)));
+    C4_TRY(hipMalloc(&sx, (size_t)C * ns_max * sizeof(int)));
+    C4_TRY(hipMalloc(&si, (size_t)C * ns_max * sizeof(int)));
+    C4_TRY(hipMalloc(&sp, (size_t)C * ns_max * sizeof(double)));
+    if (c4_stream_bytes(ns_max) > C4_LDS_STREAMS) C4_TRY(hipMalloc(&ss, (size_t)C * c4_stream_bytes(ns_max)));
+    if (b->d_y) {
+        C4_TRY(hipMemcpy2DAsync(y, (size_t)(Hy + n_max) * sizeof(double2), b->d_y,
+                                (size_t)(Hy + b->n_max) * sizeof(double2), (size_t)Hy * sizeof(double2), C,
+                                hipMemcpyDeviceToDevice, st));
+        C4_TRY(hipMemcpy2DAsync(z, (size_t)(Hz + n_max) * sizeof(float2), b->d_z,
+                                (size_t)(Hz + b->n_max) * sizeof(float2), (size_t)Hz * sizeof(float2), C,
+                                hipMemcpyDeviceToDevice, st));
+    } else {
+        C4_TRY(hipMemsetAsync(y, 0, (size_t)C * (Hy + n_max) * sizeof(double2), st));
+        C4_TRY(hipMemsetAsync(z, 0, (size_t)C * (Hz + n_max) * sizeof(float2), st));
+    }
+    C4_TRY(hipStreamSynchronize(st));   // earlier calls on this stream may still use the old workspaces
+#undef C4_TRY
+    (void)hipFree(b->d_y); (void)hipFree(b->d_z); (void)hipFree(b->d_phases); (void)hipFree(b->d_ss);
+    (void)hipFree(b->d_sym_x); (void)hipFree(b->d_sym_idx); (void)hipFree(b->d_sym_sp);
+    b->d_y = y; b->d_z = z; b->d_phases = ph; b->d_ss = ss; b->d_sym_x = sx; b->d_sym_idx = si; b->d_sym_sp = sp;
+    b->n_max = n_max; b->ns_max = ns_max;
+    return WH_OK;
+}
 
 static int c4fm_zero_state(wh_c4fm_bank *b, hipStream_t st) {
     WH_HIP(hipMemsetAsync(b->d_xh, 0, (size_t)b->C * (b->nl - 1) * sizeof(float2), st));
@@ -618,18 +699,17 @@ extern "C" int wh_c4fm_bank_create(wh_c4fm_bank **out, int C, double sps, const 
                                    const float *h_rrc, int nr, const float *h_taps, int n_max) {
     if (!out || !h_lpf || !h_rrc || !h_taps) return set_err(WH_E_ARG, "wh_c4fm_bank_create: null");
     if (C < 1 || nl < 2 || nr < 2 || nl > 1024 || nr > 2048 || !(sps >= 4.0) || sps > 512.0 || n_max < 1 ||
-        n_max > 32000)
-        return set_err(WH_E_ARG, "wh_c4fm_bank_create: need sps >= 4, 1 <= max_samples_per_call <= 32000");
+        n_max > C4_N_CAP)
+        return set_err(WH_E_ARG, "wh_c4fm_bank_create: need sps >= 4, 1 <= max_samples_per_call <= 2^24");
     wh_c4fm_bank *b = new wh_c4fm_bank();
     std::unique_ptr<wh_c4fm_bank, void (*)(wh_c4fm_bank *)> guard(b, wh_c4fm_bank_destroy);  // frees partial state on early return
-    b->C = C; b->n_max = n_max; b->nl = nl; b->nr = nr; b->sps = sps;
+    b->C = C; b->nl = nl; b->nr = nr; b->sps = sps;
     int fl = (int)floor(sps);
     b->interp_offset = fl - 4 > 0 ? fl - 4 : 0;
     b->overlap = fl + 4;
     double mu = fmod(sps, 1.0);
     int row = (int)((1.0 - mu) * 128.0 + 0.5);
     b->fm_row = row < 0 ? 0 : (row > 128 ? 128 : row);
-    b->ns_max = n_max / 4 + 16;
     WH_HIP(hipMalloc(&b->d_lpf, nl * sizeof(float)));
     WH_HIP(hipMalloc(&b->d_rrc, nr * sizeof(float)));
     WH_HIP(hipMalloc(&b->d_taps, 129 * 8 * sizeof(float)));
@@ -637,25 +717,31 @@ extern "C" int wh_c4fm_bank_create(wh_c4fm_bank **out, int C, double sps, const 
     WH_HIP(hipMemcpy(b->d_rrc, h_rrc, nr * sizeof(float), hipMemcpyHostToDevice));
     WH_HIP(hipMemcpy(b->d_taps, h_taps, 129 * 8 * sizeof(float), hipMemcpyHostToDevice));
     WH_HIP(hipMalloc(&b->d_xh, (size_t)C * (nl - 1) * sizeof(float2)));
-    WH_HIP(hipMalloc(&b->d_y, (size_t)C * (nr - 1 + n_max) * sizeof(double2)));
-    WH_HIP(hipMalloc(&b->d_z, (size_t)C * (b->overlap + n_max) * sizeof(float2)));
-    WH_HIP(hipMalloc(&b->d_phases, (size_t)C * n_max * sizeof(float)));
     WH_HIP(hipMalloc(&b->d_buffer, (size_t)C * BUF_LEN * sizeof(float)));
     WH_HIP(hipMalloc(&b->d_st, (size_t)C * sizeof(ChanState)));
-    WH_HIP(hipMalloc(&b->d_sym_x, (size_t)C * b->ns_max * sizeof(int)));
-    WH_HIP(hipMalloc(&b->d_sym_idx, (size_t)C * b->ns_max * sizeof(int)));
-    WH_HIP(hipMalloc(&b->d_sym_sp, (size_t)C * b->ns_max * sizeof(double)));
-    int rc = c4fm_zero_state(b, nullptr);
+    int rc = c4fm_resize(b, n_max, nullptr);
+    if (rc != WH_OK) return rc;
+    rc = c4fm_zero_state(b, nullptr);
     if (rc != WH_OK) return rc;
     WH_HIP(hipDeviceSynchronize());
     *out = guard.release();
     return WH_OK;
 }
 
+// Grow the bank's per-call workspaces so that calls of up to n_max samples per channel fit (never shrinks); all
+// demodulator state is kept.  Allocates and synchronises the stream: call it outside the hot path.
+extern "C" int wh_c4fm_bank_reserve(wh_c4fm_bank *b, size_t n_max, void *stream) {
+    if (!b) return set_err(WH_E_ARG, "wh_c4fm_bank_reserve: null handle");
+    if (n_max > (size_t)C4_N_CAP) return set_err(WH_E_ARG, "wh_c4fm_bank_reserve: more than 2^24 samples per call");
+    if (n_max <= (size_t)b->n_max) return WH_OK;
+    return c4fm_resize(b, (int)n_max, as_stream(stream));
+}
+
 extern "C" void wh_c4fm_bank_destroy(wh_c4fm_bank *b) {
     if (!b) return;
     (void)hipFree(b->d_lpf); (void)hipFree(b->d_rrc); (void)hipFree(b->d_taps); (void)hipFree(b->d_xh);
     (void)hipFree(b->d_y); (void)hipFree(b->d_z); (void)hipFree(b->d_phases); (void)hipFree(b->d_buffer);
+    (void)hipFree(b->d_ss);
     (void)hipFree(b->d_st); (void)hipFree(b->d_sym_x); (void)hipFree(b->d_sym_idx); (void)hipFree(b->d_sym_sp);
     delete b;
 }
@@ -675,7 +761,8 @@ extern "C" int wh_c4fm_bank_run(wh_c4fm_bank *b, const float *d_iq, size_t n, si
         return WH_OK;
     }
     if (!d_iq || !d_dibits || !d_soft) return set_err(WH_E_ARG, "wh_c4fm_bank_run: null buffer");
-    if (n > (size_t)b->n_max) return set_err(WH_E_ARG, "wh_c4fm_bank_run: n exceeds max_samples_per_call");
+    if (n > (size_t)b->n_max)
+        return set_err(WH_E_ARG, "wh_c4fm_bank_run: n exceeds max_samples_per_call (grow with wh_c4fm_bank_reserve)");
     if (iq_stride < n) return set_err(WH_E_ARG, "wh_c4fm_bank_run: iq_stride < n");
     if (out_cap < n / 4 + 2) return set_err(WH_E_ARG, "wh_c4fm_bank_run: out_cap must be >= n/4 + 2");
     C4Args a;
@@ -685,6 +772,8 @@ extern "C" int wh_c4fm_bank_run(wh_c4fm_bank *b, const float *d_iq, size_t n, si
     a.sps = b->sps; a.lagging_offset = b->sps / 2.0; a.max_fine_adj = b->sps * 0.2;
     a.nl = b->nl; a.nr = b->nr; a.overlap = b->overlap; a.interp_offset = b->interp_offset; a.fm_row = b->fm_row;
     a.ns_max = b->ns_max;
+    a.ns_call = c4_ns(b->sps, (int)n) < b->ns_max ? c4_ns(b->sps, (int)n) : b->ns_max;
+    a.ss = b->d_ss;
     a.lpf = b->d_lpf; a.rrc = b->d_rrc; a.taps = b->d_taps;
     a.xh = b->d_xh; a.y = b->d_y; a.z = b->d_z; a.phases = b->d_phases; a.buffer = b->d_buffer; a.st = b->d_st;
     a.sym_x = b->d_sym_x; a.sym_sp = b->d_sym_sp; a.sym_idx = b->d_sym_idx;
@@ -698,11 +787,15 @@ extern "C" int wh_c4fm_bank_run(wh_c4fm_bank *b, const float *d_iq, size_t n, si
     WH_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_fm, dim3(tiles, b->C), dim3(256), 0, st, a);
     WH_LAUNCH_CHECK();
-    size_t sm_s = (size_t)2 * (24 + b->ns_max) * sizeof(float);
-    if (sm_s > 64 * 1024)
-        WH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_seq), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)sm_s));
-    hipLaunchKernelGGL(k_seq, dim3(b->C), dim3(64), sm_s, st, a);
+    // symbol clock, sync search, equaliser: one wave per channel; the detector streams of a call sit in LDS when they
+    // fit 64 KB (calls up to ~8 000 symbols: 81 000 samples at 48 kS/s), in the workspace otherwise
+    const size_t sm_s = c4_stream_bytes(a.ns_call);
+    if (sm_s <= C4_LDS_STREAMS) {
+        hipLaunchKernelGGL(k_seq<false>, dim3(b->C), dim3(64), sm_s, st, a);
+    } else {
+        if (!b->d_ss) return set_err(WH_E_ARG, "wh_c4fm_bank_run: stream workspace missing");
+        hipLaunchKernelGGL(k_seq<true>, dim3(b->C), dim3(64), 0, st, a);
+    }
     WH_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_carry, dim3(b->C), dim3(256), 0, st, a);
     WH_LAUNCH_CHECK();

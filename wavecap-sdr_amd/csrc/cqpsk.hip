@@ -408,8 +408,8 @@ static int cq_reset(wh_cqpsk_bank *b, hipStream_t st) {
 extern "C" int wh_cqpsk_bank_create(wh_cqpsk_bank **out, int C, double sps, const float *h_rrc, int ntaps,
                                     const double *h_zi, double c_kp, double c_ki, double c_maxf, double t_kp,
                                     double t_ki, int n_max) {
-    if (!out || !h_rrc || !h_zi || C < 1 || ntaps < 2 || ntaps > 4096 || !(sps > 1.0) || n_max < 1)
-        return set_err(WH_E_ARG, "wh_cqpsk_bank_create: bad arguments");
+    if (!out || !h_rrc || !h_zi || C < 1 || ntaps < 2 || ntaps > 4096 || !(sps >= 2.0) || n_max < 1)
+        return set_err(WH_E_ARG, "wh_cqpsk_bank_create: bad arguments (samples_per_symbol >= 2)");
     wh_cqpsk_bank *b = new wh_cqpsk_bank();
     std::unique_ptr<wh_cqpsk_bank, void (*)(wh_cqpsk_bank *)> guard(b, wh_cqpsk_bank_destroy);  // frees partial state on early return
     b->C = C; b->n_max = n_max; b->L = ntaps; b->sps = sps;
@@ -436,6 +436,26 @@ extern "C" void wh_cqpsk_bank_destroy(wh_cqpsk_bank *b) {
     delete b;
 }
 
+// symbols a call of n samples can produce: the Mueller-Muller period is clamped to [sps / 2, ...] (integrator within
+// +-sps / 4, symbol_timing.py:330-345), bound computed in floating point (sps / 2 need not be an integer)
+static size_t mm_symbol_bound(size_t n, double sps) { return (size_t)((double)n / (sps * 0.5)) + 2; }
+
+// Grow the matched-filter workspace for calls of up to n_max samples per channel (never shrinks; no state lives in it).
+// Allocates and synchronises the stream: not for the hot path.
+extern "C" int wh_cqpsk_bank_reserve(wh_cqpsk_bank *b, size_t n_max, void *stream) {
+    if (!b) return set_err(WH_E_ARG, "wh_cqpsk_bank_reserve: null handle");
+    if (n_max > (size_t)1 << 26) return set_err(WH_E_ARG, "wh_cqpsk_bank_reserve: more than 2^26 samples per call");
+    if (n_max <= (size_t)b->n_max) return WH_OK;
+    double2 *full = nullptr;
+    WH_HIP(hipMalloc(&full, (size_t)b->C * (n_max + b->L - 1) * sizeof(double2)));
+    hipError_t e = hipStreamSynchronize(as_stream(stream));   // earlier calls may still read the old workspace
+    if (e != hipSuccess) { (void)hipFree(full); return set_err(WH_E_HIP, "wh_cqpsk_bank_reserve: %s", hipGetErrorString(e)); }
+    (void)hipFree(b->d_full);
+    b->d_full = full;
+    b->n_max = (int)n_max;
+    return WH_OK;
+}
+
 extern "C" int wh_cqpsk_bank_reset(wh_cqpsk_bank *b, void *stream) {
     if (!b) return set_err(WH_E_ARG, "wh_cqpsk_bank_reset: null handle");
     return cq_reset(b, as_stream(stream));
@@ -451,7 +471,7 @@ extern "C" int wh_cqpsk_bank_run(wh_cqpsk_bank *b, const float *d_iq, size_t n, 
     }
     if (!d_iq || !d_dibits) return set_err(WH_E_ARG, "wh_cqpsk_bank_run: null buffer");
     if (n > (size_t)b->n_max || iq_stride < n) return set_err(WH_E_ARG, "wh_cqpsk_bank_run: n too large / bad stride");
-    if (cap < (size_t)(n / (size_t)(b->sps * 0.5)) + 2) return set_err(WH_E_ARG, "wh_cqpsk_bank_run: cap too small");
+    if (cap < mm_symbol_bound(n, b->sps)) return set_err(WH_E_ARG, "wh_cqpsk_bank_run: cap too small");
     CqArgs a;
     a.iq = reinterpret_cast<const float2 *>(d_iq);
     a.iq_stride = iq_stride;
@@ -577,7 +597,7 @@ struct wh_mm_bank {
 };
 
 extern "C" int wh_mm_bank_create(wh_mm_bank **out, int C, double sps, double kp, double ki) {
-    if (!out || C < 1 || !(sps > 1.0)) return set_err(WH_E_ARG, "wh_mm_bank_create: bad arguments");
+    if (!out || C < 1 || !(sps >= 2.0)) return set_err(WH_E_ARG, "wh_mm_bank_create: bad arguments (samples_per_symbol >= 2)");
     wh_mm_bank *b = new wh_mm_bank();
     std::unique_ptr<wh_mm_bank, void (*)(wh_mm_bank *)> guard(b, wh_mm_bank_destroy);
     b->C = C; b->sps = sps; b->kp = kp; b->ki = ki;
@@ -609,7 +629,7 @@ extern "C" int wh_mm_bank_run(wh_mm_bank *b, const double *d_x, size_t n, size_t
     }
     if (!d_x || !d_symbols || !d_decisions || !d_errors || stride < n || n > 0x7fffffff)
         return set_err(WH_E_ARG, "wh_mm_bank_run: bad buffers");
-    if (cap < (size_t)(n / (size_t)(b->sps * 0.5)) + 2) return set_err(WH_E_ARG, "wh_mm_bank_run: cap too small");
+    if (cap < mm_symbol_bound(n, b->sps)) return set_err(WH_E_ARG, "wh_mm_bank_run: cap too small");
     hipLaunchKernelGGL(k_mm, dim3((unsigned)b->C), dim3(64), 0, st, reinterpret_cast<const double2 *>(d_x), stride, (int)n,
                        b->d_st, b->sps, b->kp, b->ki, reinterpret_cast<double2 *>(d_symbols),
                        reinterpret_cast<double2 *>(d_decisions), d_errors, cap, d_counts);

@@ -158,6 +158,7 @@ PROTOTYPES = {
                                      C.POINTER(c_double), c_double, c_double, c_double, c_double, c_double, c_int]),
     "wh_cqpsk_bank_run": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p, c_size_t, c_void_p,
                                   c_void_p]),
+    "wh_cqpsk_bank_reserve": (c_int, [c_void_p, c_size_t, c_void_p]),
     "wh_cqpsk_bank_reset": (c_int, [c_void_p, c_void_p]),
     "wh_cqpsk_bank_destroy": (None, [c_void_p]),
     "wh_gardner_bank_create": (c_int, [C.POINTER(c_void_p), c_int, c_double, c_double, c_double]),
@@ -169,6 +170,7 @@ PROTOTYPES = {
                                     C.POINTER(c_float), c_int, C.POINTER(c_float), c_int]),
     "wh_c4fm_bank_run": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p, c_size_t,
                                  c_void_p, c_void_p]),
+    "wh_c4fm_bank_reserve": (c_int, [c_void_p, c_size_t, c_void_p]),
     "wh_c4fm_bank_reset": (c_int, [c_void_p, c_void_p]),
     "wh_c4fm_bank_destroy": (None, [c_void_p]),
 }

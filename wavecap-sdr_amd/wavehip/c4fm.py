@@ -7,6 +7,11 @@ wavecapsdr.dsp.p25.c4fm.C4FMDemodulator (c4fm.py:2379-2807) plus a batched bank.
 between calls, exactly one instance per channel like the reference (control_channel.py:230).
 `C4FMBank` runs C independent demodulators per launch (BASELINE.json configs[3]).
 
+Call size: one `demodulate(iq)` here is one `demodulate(iq)` there, whatever `len(iq)` is -- the reference's block
+processing is not invariant to where a stream is cut (c4fm.py:704-728, 2621-2770; the control-channel monitor calls it
+with 72 000-75 000 samples, trunking/system.py:1548-1549), so a call is never split; `max_samples_per_call` only sizes
+the device workspaces and grows on demand.
+
 Filter designs are the reference's own host-side designs (design_baseband_lpf c4fm.py:95-132,
 design_rrc_filter :135-183); the 129x8 MMSE interpolator table (:907-2202, GNU Radio /
 SDRTrunk constants) ships as a binary data file."""
@@ -78,11 +83,24 @@ class C4FMBank:
             _lib.dptr(self._baseband_lpf, "f32"), len(self._baseband_lpf),
             _lib.dptr(self._rrc_filter, "f32"), len(self._rrc_filter), _lib.dptr(taps, "f32"),
             self.max_samples_per_call), "wh_c4fm_bank_create")
-        self.out_cap = self.max_samples_per_call // 4 + 16
+        self._counts = self._torch.zeros(self.n_channels, dtype=self._torch.int32, device="cuda")
+        self._size_outputs()
+
+    def _size_outputs(self) -> None:
         torch = self._torch
+        self.out_cap = self.max_samples_per_call // 4 + 16
         self._dibits = torch.empty((self.n_channels, self.out_cap), dtype=torch.uint8, device="cuda")
         self._soft = torch.empty((self.n_channels, self.out_cap), dtype=torch.float32, device="cuda")
-        self._counts = torch.zeros(self.n_channels, dtype=torch.int32, device="cuda")
+
+    def reserve(self, max_samples_per_call: int) -> None:
+        """Grow the bank for calls of up to `max_samples_per_call` samples per channel (allocates; all demodulator state
+        is kept).  Done implicitly by a longer call; call it up front to keep allocation out of the first long call."""
+        if max_samples_per_call <= self.max_samples_per_call:
+            return
+        _lib.check(_lib.lib.wh_c4fm_bank_reserve(self._h, int(max_samples_per_call), _lib.stream_ptr(self._torch)),
+                   "wh_c4fm_bank_reserve")
+        self.max_samples_per_call = int(max_samples_per_call)
+        self._size_outputs()
 
     def __del__(self):
         h, destroy = getattr(self, "_h", None), getattr(self, "_destroy", None)
@@ -94,13 +112,16 @@ class C4FMBank:
         _lib.check(_lib.lib.wh_c4fm_bank_reset(self._h, _lib.stream_ptr(self._torch)), "wh_c4fm_bank_reset")
 
     def demodulate_device(self, iq_dev):
-        """iq_dev: complex64 GPU tensor [C, n] (n <= max_samples_per_call).  Returns GPU tensors
+        """iq_dev: complex64 GPU tensor [C, n] = ONE reference call per channel (a longer n than any before grows the
+        workspaces first).  Returns GPU tensors
         (dibits uint8 [C, cap], soft float32 [C, cap], counts int32 [C]); rows are valid up to counts[c]
         and are overwritten by the next call."""
         torch = self._torch
         assert iq_dev.is_cuda and iq_dev.dtype == torch.complex64 and iq_dev.dim() == 2
         assert iq_dev.shape[0] == self.n_channels and iq_dev.stride(1) == 1
         n = iq_dev.shape[1]
+        if n > self.max_samples_per_call:
+            self.reserve(n)
         row_stride = iq_dev.stride(0) if self.n_channels > 1 else n   # a size-1 dim may report any stride
         _lib.check(_lib.lib.wh_c4fm_bank_run(self._h, iq_dev.data_ptr(), n, row_stride,
                                              self._dibits.data_ptr(), self._soft.data_ptr(), self.out_cap,
@@ -114,15 +135,9 @@ class C4FMBank:
         assert x.ndim == 2 and x.shape[0] == self.n_channels
         if x.shape[1] == 0:
             return [(np.array([], dtype=np.uint8), np.array([], dtype=np.float32))] * self.n_channels
-        out = [([], []) for _ in range(self.n_channels)]
-        for s in range(0, x.shape[1], self.max_samples_per_call):
-            part = np.ascontiguousarray(x[:, s:s + self.max_samples_per_call])
-            d, sf, cnt = self.demodulate_device(torch.from_numpy(part).cuda())
-            d, sf, cnt = d.cpu().numpy(), sf.cpu().numpy(), cnt.cpu().numpy()
-            for c in range(self.n_channels):
-                out[c][0].append(d[c, :cnt[c]].copy())
-                out[c][1].append(sf[c, :cnt[c]].copy())
-        return [(np.concatenate(a), np.concatenate(b)) for a, b in out]
+        d, sf, cnt = self.demodulate_device(torch.from_numpy(x).cuda())
+        d, sf, cnt = d.cpu().numpy(), sf.cpu().numpy(), cnt.cpu().numpy()
+        return [(d[c, :cnt[c]].copy(), sf[c, :cnt[c]].copy()) for c in range(self.n_channels)]
 
 
 class C4FMDemodulator:
@@ -133,7 +148,7 @@ class C4FMDemodulator:
         self.sample_rate, self.symbol_rate, self.wide_pulse = sample_rate, symbol_rate, wide_pulse
         self.samples_per_symbol = sample_rate / symbol_rate
         self._bank = C4FMBank(1, sample_rate, symbol_rate, wide_pulse,
-                              max_samples_per_call=int(kwargs.get("max_samples_per_call", 16384)))
+                              max_samples_per_call=int(kwargs.get("max_samples_per_call", 81920)))
 
     @property
     def _ted_phase(self) -> float:  # c4fm.py:2523-2526

@@ -61,11 +61,24 @@ class CQPSKBank:
                                                  _lib.dptr(self._rrc, "f32"), len(self._rrc), _lib.dptr(zi, "f64"),
                                                  ckp, cki, 0.1, tkp, tki, self.max_samples_per_call),
                    "wh_cqpsk_bank_create")
+        self._counts = self._torch.zeros(self.n_channels, dtype=self._torch.int32, device="cuda")
+        self._symbols = None
+        self._size_outputs()
+
+    def _size_outputs(self) -> None:
         torch = self._torch
         self.cap = int(self.max_samples_per_call / (self.samples_per_symbol * 0.5)) + 8
         self._dibits = torch.empty((self.n_channels, self.cap), dtype=torch.uint8, device="cuda")
-        self._symbols = torch.empty((self.n_channels, self.cap), dtype=torch.complex128, device="cuda")
-        self._counts = torch.zeros(self.n_channels, dtype=torch.int32, device="cuda")
+        self._symbols = None        # complex128 [C, cap], allocated when symbols are first asked for
+
+    def reserve(self, max_samples_per_call: int) -> None:
+        """Grow the bank for calls of up to `max_samples_per_call` samples per channel (allocates; state is kept)."""
+        if max_samples_per_call <= self.max_samples_per_call:
+            return
+        _lib.check(_lib.lib.wh_cqpsk_bank_reserve(self._h, int(max_samples_per_call), _lib.stream_ptr(self._torch)),
+                   "wh_cqpsk_bank_reserve")
+        self.max_samples_per_call = int(max_samples_per_call)
+        self._size_outputs()
 
     def __del__(self):
         h, destroy = getattr(self, "_h", None), getattr(self, "_destroy", None)
@@ -81,6 +94,10 @@ class CQPSKBank:
         assert iq_dev.is_cuda and iq_dev.dtype == torch.complex64 and iq_dev.dim() == 2
         assert iq_dev.shape[0] == self.n_channels and iq_dev.stride(1) == 1
         n = iq_dev.shape[1]
+        if n > self.max_samples_per_call:       # one call of the reference == one launch, whatever its length
+            self.reserve(n)
+        if want_symbols and self._symbols is None:
+            self._symbols = torch.empty((self.n_channels, self.cap), dtype=torch.complex128, device="cuda")
         stride = iq_dev.stride(0) if self.n_channels > 1 else n
         _lib.check(_lib.lib.wh_cqpsk_bank_run(self._h, iq_dev.data_ptr(), n, stride, self._dibits.data_ptr(),
                                               self._symbols.data_ptr() if want_symbols else None, self.cap,
@@ -88,22 +105,21 @@ class CQPSKBank:
         return self._dibits, self._symbols, self._counts
 
     def demodulate(self, iq, want_symbols: bool = False):
+        """iq: complex [C, n] on the host -> per channel dibits (and complex128 symbols).  The whole block is ONE
+        reference call: the chain re-seeds its matched filter with zi * iq[0] per call (cqpsk.py:283-285), so a block is
+        never cut into pieces here; a block longer than `max_samples_per_call` grows the bank."""
         torch = self._torch
         x = np.ascontiguousarray(iq, dtype=np.complex64)
         assert x.ndim == 2 and x.shape[0] == self.n_channels
-        outs = [([], []) for _ in range(self.n_channels)]
-        for s in range(0, x.shape[1], self.max_samples_per_call):
-            part = np.ascontiguousarray(x[:, s:s + self.max_samples_per_call])
-            d, sy, cnt = self.demodulate_device(torch.from_numpy(part).cuda(), want_symbols)
-            d, cnt = d.cpu().numpy(), cnt.cpu().numpy()
-            sy = sy.cpu().numpy() if want_symbols else None
-            for c in range(self.n_channels):
-                outs[c][0].append(d[c, :cnt[c]].copy())
-                if want_symbols:
-                    outs[c][1].append(sy[c, :cnt[c]].copy())
+        if x.shape[1] == 0:
+            e = np.array([], np.uint8)
+            return [(e, np.zeros(0, np.complex128)) if want_symbols else e for _ in range(self.n_channels)]
+        d, sy, cnt = self.demodulate_device(torch.from_numpy(x).cuda(), want_symbols)
+        d, cnt = d.cpu().numpy(), cnt.cpu().numpy()
+        sy = sy.cpu().numpy() if want_symbols else None
         if want_symbols:
-            return [(np.concatenate(a), np.concatenate(b)) for a, b in outs]
-        return [np.concatenate(a) if a else np.array([], np.uint8) for a, _ in outs]
+            return [(d[c, :cnt[c]].copy(), sy[c, :cnt[c]].copy()) for c in range(self.n_channels)]
+        return [d[c, :cnt[c]].copy() for c in range(self.n_channels)]
 
 
 class CQPSKDemodulator:
@@ -271,7 +287,7 @@ class MuellerMullerBank:
         assert x_dev.is_cuda and x_dev.dtype == torch.complex128 and x_dev.dim() == 2 and x_dev.shape[0] == self.n_channels
         x_dev = x_dev.contiguous()
         n = x_dev.shape[1]
-        cap = int(n / (self.samples_per_symbol * 0.5)) + 4
+        cap = int(n / (self.samples_per_symbol * 0.5)) + 8     # >= the library's bound n / (sps / 2) + 2, in floating point
         sym = torch.empty((self.n_channels, cap), dtype=torch.complex128, device=x_dev.device)
         dec = torch.empty((self.n_channels, cap), dtype=torch.complex128, device=x_dev.device)
         err = torch.empty((self.n_channels, cap), dtype=torch.float64, device=x_dev.device)
