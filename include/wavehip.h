@@ -147,6 +147,12 @@ int wh_chanbank_run(wh_chanbank *b, const void *d_in, size_t n_chunks, float *d_
  * both buffers.  Only d_wire (and the 16-byte metrics rows) need to cross PCIe. */
 int wh_chanbank_run_wire(wh_chanbank *b, const void *d_in, size_t n_chunks, float *d_audio, float *d_metrics,
                          int wire_format, void *d_wire, void *stream);
+/* Retune / re-squelch a live bank (API PATCH of a channel's offset_hz or squelch_db -> capture.py:442-501 cfg update;
+ * the reference's stateless operator reads cfg.offset_hz on every chunk, capture.py:326-329): one small host-to-device
+ * copy enqueued on `stream` -- launches queued before it keep the old values -- no allocation, no synchronisation.
+ * h_offsets_hz: round(offset_hz) per channel, 0 = no mix; h_squelch_db: NaN = none (bank created with h_squelch_db). */
+int wh_chanbank_set_offsets(wh_chanbank *b, const int *h_offsets_hz, int n_channels, void *stream);
+int wh_chanbank_set_squelch(wh_chanbank *b, const float *h_squelch_db, int n_channels, void *stream);
 size_t wh_chanbank_workspace_bytes(const wh_chanbank *b, size_t n_chunks);
 void wh_chanbank_destroy(wh_chanbank *b);
 

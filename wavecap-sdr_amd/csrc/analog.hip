@@ -1649,6 +1649,8 @@ struct wh_chanbank {
     wh_chanbank_cfg cfg;
     float *d_nco = nullptr;
     float *d_squelch = nullptr;
+    std::vector<float> h_stage[2];   // host side of wh_chanbank_set_offsets / _set_squelch (alternating, kept alive)
+    int h_stage_cur = 0;
     double *d_taps = nullptr;
     StageArr stages{};
     ScanPow *d_pow = nullptr;   // scan form: per-stage state-transition powers for the bank's segment length
@@ -1670,6 +1672,31 @@ struct wh_chanbank {
     float *d_nr_win = nullptr, *d_nr_mag = nullptr, *d_nr_sel = nullptr;
     float2 *d_nr_tw = nullptr, *d_nr_stft = nullptr;
 };
+
+// Retune without rebuilding the bank (API PATCH of offset_hz -> capture.py:442-501): the mixer constant is one float32
+// per channel in a device array, nothing else in the bank depends on the offsets.  The copy is enqueued on `stream`, so
+// launches already queued there keep the old offsets and later ones see the new; no allocation, no synchronisation.
+extern "C" int wh_chanbank_set_offsets(wh_chanbank *b, const int *h_offsets_hz, int n_channels, void *stream) {
+    if (!b || !h_offsets_hz) return set_err(WH_E_ARG, "wh_chanbank_set_offsets: null");
+    if (n_channels != b->cfg.n_channels) return set_err(WH_E_ARG, "wh_chanbank_set_offsets: the bank has %d channels", b->cfg.n_channels);
+    std::vector<float> &h = b->h_stage[b->h_stage_cur ^= 1];
+    h.resize((size_t)n_channels);
+    for (int k = 0; k < n_channels; ++k) h[k] = h_offsets_hz[k] == 0 ? 0.0f : nco_const(h_offsets_hz[k], b->cfg.sample_rate);
+    WH_HIP(hipMemcpyAsync(b->d_nco, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice, as_stream(stream)));
+    return WH_OK;
+}
+
+// New squelch thresholds (float32 dB per channel, NaN = none) for a bank created with h_squelch_db.
+extern "C" int wh_chanbank_set_squelch(wh_chanbank *b, const float *h_squelch_db, int n_channels, void *stream) {
+    if (!b || !h_squelch_db) return set_err(WH_E_ARG, "wh_chanbank_set_squelch: null");
+    if (n_channels != b->cfg.n_channels || !b->d_squelch)
+        return set_err(WH_E_ARG, "wh_chanbank_set_squelch: the bank has %d channels and %s squelch array", b->cfg.n_channels,
+                       b->d_squelch ? "a" : "no");
+    std::vector<float> &h = b->h_stage[b->h_stage_cur ^= 1];
+    h.assign(h_squelch_db, h_squelch_db + n_channels);
+    WH_HIP(hipMemcpyAsync(b->d_squelch, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice, as_stream(stream)));
+    return WH_OK;
+}
 
 extern "C" int wh_chanbank_create(wh_chanbank **out, const wh_chanbank_cfg *c) {
     if (!out || !c || !c->h_offsets_hz) return set_err(WH_E_ARG, "wh_chanbank_create: null");

@@ -99,6 +99,8 @@ PROTOTYPES = {
     "wh_chanbank_create": (c_int, [C.POINTER(c_void_p), C.POINTER(ChanBankCfg)]),
     "wh_chanbank_run": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "wh_chanbank_run_wire": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "wh_chanbank_set_offsets": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    "wh_chanbank_set_squelch": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "wh_chanbank_workspace_bytes": (c_size_t, [c_void_p, c_size_t]),
     "wh_chanbank_destroy": (None, [c_void_p]),
     "wh_channel_signal_metrics": (c_int, [c_void_p, c_int, c_size_t, c_int, C.POINTER(c_int), c_int, C.POINTER(c_float),

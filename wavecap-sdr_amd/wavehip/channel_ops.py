@@ -264,6 +264,15 @@ def _chain_key(cfg):
             bool(getattr(cfg, "enable_noise_reduction", False)), float(getattr(cfg, "noise_reduction_db", 12.0)))
 
 
+def _offsets_i32(cfgs) -> np.ndarray:
+    """round(offset_hz) per channel; exactly 0.0 means "no mix" (capture.py:326-329)."""
+    return np.array([int(round(float(c.offset_hz))) if float(c.offset_hz) != 0.0 else 0 for c in cfgs], dtype=np.int32)
+
+
+def _squelch_key(cfgs) -> tuple:
+    return tuple(None if getattr(c, "squelch_db", None) is None else float(c.squelch_db) for c in cfgs)
+
+
 class ChannelBank:
     """All channels of one capture that share one chain (mode + filter settings + audio rate)."""
 
@@ -294,8 +303,9 @@ class ChannelBank:
         self.input_format = {"cf32": 0, "int16": 1}[input_format]
         self._torch = _lib.require_gpu()
         demod, bfo, stages, agc, post = build_chain(c0, self.sample_rate)
-        offs = np.array([int(round(float(c.offset_hz))) if float(c.offset_hz) != 0.0 else 0 for c in cfgs],
-                        dtype=np.int32)
+        offs = _offsets_i32(cfgs)
+        self.offsets = tuple(int(v) for v in offs)
+        self.squelch = None
         cfg = _lib.ChanBankCfg()
         cfg.sample_rate, cfg.chunk_len, cfg.n_channels = self.sample_rate, self.chunk_len, self.K
         cfg.h_offsets_hz = _lib.dptr(offs, "i32")
@@ -325,6 +335,7 @@ class ChannelBank:
                           dtype=np.float32)
             cfg.h_squelch_db = _lib.dptr(sq, "f32")
             keep.append(sq)
+            self.squelch = _squelch_key(cfgs)
         n_fm = self.chunk_len
         if self.mode in ("nbfm", "wbfm") and getattr(c0, "enable_noise_reduction", False):
             # dsp/filters.py:346-460 between the filters and rms_normalize (dsp/fm.py:303-304, 399-400); the row
@@ -362,6 +373,26 @@ class ChannelBank:
         if h and destroy:
             destroy(h)
             self._h = None
+
+    def set_offsets(self, offsets_hz) -> None:
+        """Retune the bank's channels (API PATCH of offset_hz -> capture.py:442-501; the reference's operator reads
+        cfg.offset_hz per chunk, capture.py:326-329): one 4 K-byte copy enqueued on the current stream, nothing is rebuilt.
+        Rounding and the `offset_hz == 0.0 -> no mix` rule are the constructor's."""
+        offs = np.array([int(round(float(o))) if float(o) != 0.0 else 0 for o in offsets_hz], dtype=np.int32)
+        if offs.shape[0] != self.K:
+            raise ValueError(f"ChannelBank.set_offsets: the bank has {self.K} channels")
+        _lib.check(_lib.lib.wh_chanbank_set_offsets(self._h, offs.ctypes.data, self.K, _lib.stream_ptr(self._torch)),
+                   "wh_chanbank_set_offsets")
+        self.offsets = tuple(int(v) for v in offs)
+
+    def set_squelch(self, squelch_db) -> None:
+        """New squelch thresholds (None = no squelch for that channel) for a bank created with apply_squelch=True."""
+        sq = np.array([np.nan if v is None else float(v) for v in squelch_db], dtype=np.float32)
+        if sq.shape[0] != self.K:
+            raise ValueError(f"ChannelBank.set_squelch: the bank has {self.K} channels")
+        _lib.check(_lib.lib.wh_chanbank_set_squelch(self._h, sq.ctypes.data, self.K, _lib.stream_ptr(self._torch)),
+                   "wh_chanbank_set_squelch")
+        self.squelch = tuple(None if v is None else float(v) for v in squelch_db)
 
     WIRE = {None: 0, "pcm16": 1, "f32": 2}
 
@@ -557,8 +588,12 @@ class ChannelDispatcher:
     "raw" and the digital-voice modes (metrics only) ride along.  `process(samples, cfgs)` returns
     [(audio | None, metrics)] in the order of `cfgs`, with the conventions of _process_channel_dsp_stateless;
     the stateful tail (RDS / POCSAG / P25 decoders, audio metrics) stays with the caller, squelch can be fused
-    (`apply_squelch=True`).  Banks are cached per (chunk length, chain, offsets): a channel set that does not
-    change costs no set-up after the first chunk."""
+    (`apply_squelch=True`).  Banks are cached per (chunk length, chain, channel count): a channel set that does not
+    change costs no set-up after the first chunk, and a RETUNE (offset_hz / squelch_db changed by an API PATCH,
+    capture.py:442-501) costs one 4 K-byte copy (`ChannelBank.set_offsets`), not a new bank.
+    `process` holds the dispatcher's lock for the whole chunk: the seam submits chunks to a multi-worker executor and
+    cannot cancel a job that is already running after a timeout, so two chunks may be in flight at once; the banks
+    own device scratch and queue onto one stream, so they run one chunk at a time, in submission order of the lock."""
 
     def __init__(self, sample_rate: int, apply_squelch: bool = False, max_banks: int = 32):
         self._torch = _lib.require_gpu()
@@ -566,11 +601,12 @@ class ChannelDispatcher:
         self.apply_squelch = bool(apply_squelch)
         self.max_banks = int(max_banks)
         self._banks: dict[tuple, ChannelBank] = {}
+        self._lock = threading.Lock()
+        self.banks_created = 0
 
     def process(self, samples, cfgs, snr: bool = False) -> list[tuple[np.ndarray | None, dict[str, Any]]]:
         """snr=True adds "snr_db" (Channel.update_signal_metrics, capture.py:776-796) to every channel's metrics from
         ONE ranking of the uploaded chunk's magnitudes (no second mix pass, see update_signal_metrics)."""
-        torch = self._torch
         cfgs = list(cfgs)
         if not cfgs:
             return []
@@ -581,6 +617,11 @@ class ChannelDispatcher:
         if not np.isfinite(x.view(np.float32)).all():          # capture.py:323-325, once for all channels
             logger.warning("ChannelDispatcher: non-finite IQ samples, dropping DSP chunk")
             return [(None, {}) for _ in cfgs]
+        with self._lock:
+            return self._process_locked(x, n, cfgs, snr)
+
+    def _process_locked(self, x, n, cfgs, snr):
+        torch = self._torch
         results: list[Any] = [None] * len(cfgs)
         groups: dict[tuple, list[int]] = {}
         for i, c in enumerate(cfgs):
@@ -593,18 +634,7 @@ class ChannelDispatcher:
             groups.setdefault(_chain_key(c), []).append(i)
         if groups:
             d_in = torch.from_numpy(x).cuda()
-            launched = []
-            for key, idx in groups.items():
-                offs = tuple(int(round(float(cfgs[i].offset_hz))) for i in idx)
-                sq = tuple(getattr(cfgs[i], "squelch_db", None) for i in idx) if self.apply_squelch else ()
-                bkey = (n, key, offs, sq)
-                bank = self._banks.get(bkey)
-                if bank is None:
-                    if len(self._banks) >= self.max_banks:
-                        self._banks.pop(next(iter(self._banks)))
-                    bank = self._banks[bkey] = ChannelBank(self.sample_rate, n, [cfgs[i] for i in idx],
-                                                           apply_squelch=self.apply_squelch)
-                launched.append((bank, idx, bank.process_device(d_in, 1)))    # all groups queued before any read-back
+            launched = self._launch_groups(d_in, n, cfgs, groups)        # all groups queued before any read-back
             snr_db = update_signal_metrics(d_in, self.sample_rate, [0.0])[0]["snr_db"] if snr else None
             for bank, idx, (audio, met) in launched:
                 for i, r in zip(idx, bank.collect(audio, met)):
@@ -612,6 +642,76 @@ class ChannelDispatcher:
                         r[1]["snr_db"] = snr_db
                     results[i] = r
         return results
+
+    def _launch_groups(self, d_in, n, cfgs, groups):
+        launched = []
+        for key, idx in groups.items():
+            group = [cfgs[i] for i in idx]
+            offs = tuple(int(v) for v in _offsets_i32(group))
+            sq = _squelch_key(group) if self.apply_squelch else None
+            has_sq = sq is not None and any(v is not None for v in sq)
+            bkey = (n, key, len(idx), has_sq)
+            bank = self._banks.get(bkey)
+            if bank is None:
+                if len(self._banks) >= self.max_banks:
+                    self._banks.pop(next(iter(self._banks)))
+                bank = self._banks[bkey] = ChannelBank(self.sample_rate, n, group, apply_squelch=self.apply_squelch)
+                self.banks_created += 1
+            else:
+                if bank.offsets != offs:            # retune: one small copy, nothing rebuilt
+                    bank.set_offsets(offs)
+                if has_sq and bank.squelch != sq:
+                    bank.set_squelch(sq)
+            launched.append((bank, idx, bank.process_device(d_in, 1)))
+        return launched
+
+    ROW_EXTRA = 5       # process_device rows: [audio (row_len) | rssi_db, signal_power_db, max |audio|, finite | n_out]
+
+    def process_device(self, d_in, cfgs, row_len: int | None = None):
+        """Device-resident form for callers that keep results on the GPU (the channel split's gather, wire packing):
+        `d_in` complex64 GPU tensor of one chunk -> ONE float32 GPU tensor [len(cfgs), row_len + 5], row i = channel
+        i's audio (zero padded to row_len = the longest row unless given), then the finalize kernel's four metrics
+        (rssi_db, signal_power_db, max |audio|, all-finite flag) and the row's audio length.  Nothing is downloaded, no
+        validation is applied (`rows_to_results` does both on whichever rank consumes the rows).  Analog chains only
+        ("raw" / digital-voice channels produce host results: use process())."""
+        torch = self._torch
+        cfgs = list(cfgs)
+        assert d_in.is_cuda and d_in.dtype == torch.complex64 and d_in.dim() == 1 and d_in.is_contiguous()
+        n = d_in.shape[0]
+        groups: dict[tuple, list[int]] = {}
+        for i, c in enumerate(cfgs):
+            why = "mode 'raw' / digital voice in the device-resident form" if (c.mode == "raw" or c.mode in DIGITAL_MODES) else _unsupported(c)
+            if why:
+                raise NotImplementedError(f"wavehip: {why} is not implemented on the device")
+            groups.setdefault(_chain_key(c), []).append(i)
+        with self._lock:
+            launched = self._launch_groups(d_in, n, cfgs, groups)
+            need = max((b.n_out for b, _, _ in launched), default=0)
+            L = need if row_len is None else int(row_len)
+            if L < need:
+                raise ValueError(f"ChannelDispatcher.process_device: row_len {L} < longest audio row {need}")
+            rows = torch.zeros((len(cfgs), L + self.ROW_EXTRA), dtype=torch.float32, device=d_in.device)
+            for bank, idx, (audio, met) in launched:
+                ii = torch.as_tensor(idx, device=d_in.device)
+                rows[ii, :bank.n_out] = audio[0]
+                rows[ii, L:L + 4] = met[0]
+                rows[ii, L + 4] = float(bank.n_out)
+        return rows
+
+    @classmethod
+    def rows_to_results(cls, rows) -> list[tuple[np.ndarray | None, dict[str, Any]]]:
+        """process_device rows (any device) -> the reference's [(audio | None, metrics)] (validation.py:41-52 applied)."""
+        r = rows.cpu().numpy()
+        L = r.shape[1] - cls.ROW_EXTRA
+        out = []
+        for k in range(r.shape[0]):
+            m: dict[str, Any] = {"rssi_db": float(r[k, L])}
+            if r[k, L + 3] < 0.5 or r[k, L + 2] > AUDIO_MAX_ABS:
+                out.append((None, m))
+                continue
+            m["signal_power_db"] = float(r[k, L + 1])
+            out.append((r[k, :int(r[k, L + 4])].copy(), m))
+        return out
 
 
 def noise_blanker(x, threshold_db: float = 10.0, blanking_width: int = 3) -> np.ndarray:
