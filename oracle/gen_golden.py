@@ -723,6 +723,66 @@ def gen_cqpsk_big():
     save("cqpsk_big", **out)
 
 
+def gen_caprate():
+    """A14 at CAPTURE rates (250 kS/s, 2.4 MS/s), where the live loop runs AM / SSB / SAM channels
+    (capture.py:298-439 on chunks of max(8192, fs // 20) samples).  The reference's order-5 ba-form Butterworths are
+    ill-conditioned there: what IS reproducible is the OUTCOME CLASS the live loop acts on -- audio or
+    None (validate_audio_samples, validation.py:41-52 -> capture.py:323-325, 2593-2595) -- and the metrics.  Per case:
+    class, rssi_db / signal_power_db, the audio, and the measured sensitivity of that audio to a +-1-ulp perturbation of
+    the input (`sens`, peak-relative; the class under the perturbation must not change or the case is dropped): the
+    device must reproduce class and metrics, and the audio to max(1e-5, 4 * sens) wherever sens < 1e-3."""
+    out = {}
+    cases = []
+    for fs in (250_000, 2_400_000):
+        n = max(8192, fs // 20)
+        car = 30_000.0
+        cases += [
+            (f"am{fs // 1000}", fs, n, 580, "am", car, car, dict()),
+            (f"am{fs // 1000}_nohp", fs, n, 581, "am", car, car, dict(enable_am_highpass=False)),
+            (f"am{fs // 1000}_noagc", fs, n, 582, "am", car, car, dict(enable_agc=False)),
+            (f"usb{fs // 1000}", fs, n, 583, "ssb", car + 1200.0, car, dict(ssb_mode="usb")),
+            (f"lsb{fs // 1000}", fs, n, 584, "ssb", car - 900.0, car, dict(ssb_mode="lsb")),
+            (f"sam{fs // 1000}", fs, n, 585, "sam", car + 12.0, car, dict()),
+            (f"sam{fs // 1000}_usb", fs, n, 586, "sam", car - 8.0, car, dict(sam_sideband="usb")),
+        ]
+    kept = []
+    for tag, fs, n, seed, mode, sig_car, off, kw in cases:
+        iq = S.am_tone_c64(n, fs, seed=seed, carrier_hz=sig_car, depth=0.7)
+        cfg = rc.ChannelConfig(id="c", capture_id="c", mode=mode, offset_hz=off, **kw)
+        rc._get_freq_shift_exp.cache_clear()
+        audio, met = rc._process_channel_dsp_stateless(iq, fs, cfg)
+        # +-1 ulp on a random half of the float32 components
+        rng = np.random.default_rng(seed + 1)
+        f = iq.view(np.float32).copy()
+        pick = rng.random(f.size) < 0.5
+        f[pick] = np.nextafter(f[pick], np.where(rng.random(int(pick.sum())) < 0.5, np.float32(np.inf), np.float32(-np.inf)).astype(np.float32))
+        rc._get_freq_shift_exp.cache_clear()
+        audio2, met2 = rc._process_channel_dsp_stateless(f.view(np.complex64), fs, cfg)
+        cls, cls2 = audio is not None, audio2 is not None
+        sens = float("nan")
+        if cls and cls2:
+            sens = float(np.max(np.abs(audio - audio2)) / max(float(np.max(np.abs(audio))), 1e-30))
+        print(f"  caprate {tag}: audio={'yes' if cls else 'None'} (perturbed: {'yes' if cls2 else 'None'}) "
+              f"rssi={met.get('rssi_db'):.4f} sp={met.get('signal_power_db')} sens={sens:.3g} "
+              f"peak={float(np.max(np.abs(audio))) if cls else float('nan'):.4g}")
+        if cls != cls2:
+            print(f"    -> class not stable under +-1 ulp: dropped")
+            continue
+        kept.append(tag)
+        out[f"{tag}_sha"] = np.array(S.sha256(iq))
+        out[f"{tag}_args"] = np.array([fs, n, seed, sig_car, off], dtype=np.float64)
+        out[f"{tag}_mode"] = np.array(mode)
+        out[f"{tag}_kw"] = np.array(repr(kw))
+        out[f"{tag}_class"] = np.array(int(cls))
+        out[f"{tag}_met"] = np.array([met["rssi_db"], met.get("signal_power_db", np.nan)])
+        out[f"{tag}_met_pert"] = np.array([met2["rssi_db"], met2.get("signal_power_db", np.nan)])
+        out[f"{tag}_sens"] = np.array(sens)
+        if cls:
+            out[f"{tag}_audio"] = audio
+    out["tags"] = np.array(kept)
+    save("chain_caprate", **out)
+
+
 def gen_blanker():
     """A14: noise_blanker (dsp/filters.py:267-343) on float32 audio with impulses; even and odd lengths."""
     from wavecapsdr.dsp.filters import noise_blanker
@@ -892,7 +952,7 @@ def gen_lsm():
     save("lsm", **out)
 
 
-ALL = dict(c4fm_big=gen_c4fm_big, cqpsk_big=gen_cqpsk_big, status=gen_status, cqpsk_parts=gen_cqpsk_parts, chain4=gen_chain4, blanker=gen_blanker, nid=gen_nid, classifier=gen_classifier, recorder=gen_recorder, nr=gen_nr, sam=gen_sam, rawdig=gen_rawdig, lsm=gen_lsm, framer=gen_framer, cqpsk=gen_cqpsk, trunk=gen_trunk, a1=gen_a1, a2=gen_a2, a3=gen_a3, a6=gen_a6, chain=gen_chain, a7=gen_a7, a8=gen_a8, c4fm=gen_c4fm)
+ALL = dict(caprate=gen_caprate, c4fm_big=gen_c4fm_big, cqpsk_big=gen_cqpsk_big, status=gen_status, cqpsk_parts=gen_cqpsk_parts, chain4=gen_chain4, blanker=gen_blanker, nid=gen_nid, classifier=gen_classifier, recorder=gen_recorder, nr=gen_nr, sam=gen_sam, rawdig=gen_rawdig, lsm=gen_lsm, framer=gen_framer, cqpsk=gen_cqpsk, trunk=gen_trunk, a1=gen_a1, a2=gen_a2, a3=gen_a3, a6=gen_a6, chain=gen_chain, a7=gen_a7, a8=gen_a8, c4fm=gen_c4fm)
 
 if __name__ == "__main__":
     import logging

@@ -634,8 +634,11 @@ def spectrum(iq: np.ndarray, sample_rate: int, fft_size: int):
 def pfb_channel_stats(out: np.ndarray) -> np.ndarray:
     """Per-channel {sum p, sum p^2, count, min p, max p} of p=|y|^2 over hops, the
     BinStats fields of channel_classifier.py:17-48 applied to filterbank channels.
-    Returns float64[M, 5]."""
-    p = (out.real.astype(np.float64) ** 2 + out.imag.astype(np.float64) ** 2)
+    Returns float64[M, 5].  Definition (round 3): p is taken in FLOAT32, p = f32(f32(re^2) + f32(im^2)) -- min / max are
+    therefore exact float32 values -- and the sums are sums of those float32 p (here in float64; the device adds short
+    float32 blocks in float64 and agrees to <= 2e-6 relative)."""
+    re, im = out.real.astype(np.float32), out.imag.astype(np.float32)
+    p = (re * re + im * im).astype(np.float64)          # float32 products, float32 sum (numpy keeps float32 here)
     H = p.shape[0]
     return np.stack([p.sum(0), (p * p).sum(0), np.full(p.shape[1], float(H)), p.min(0), p.max(0)], axis=1)
 

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import signals as S
-from conftest import peak_rel_err
+from conftest import db_close, peak_rel_err, record_margin
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -127,13 +127,13 @@ def test_chain_nbfm_golden_int16_bank(wh, golden, O):
         for k in g["nbfm_k"]:
             audio, met = res[int(k)]
             assert peak_rel_err(audio, g[f"nbfm{chunk}_k{k}_audio"]) <= TOL
-            assert np.allclose([met["rssi_db"], met["signal_power_db"]], g[f"nbfm{chunk}_k{k}_met"], atol=2e-4)
+            assert db_close([met["rssi_db"], met["signal_power_db"]], g[f"nbfm{chunk}_k{k}_met"])
         if chunk == 0:
             z = O.unpack_iq16(i16)
             for k in range(32):
                 a_ref, m_ref = O.process_channel_nbfm(z, fs, offs[k])
                 assert peak_rel_err(res[k][0], a_ref) <= TOL, k
-                assert abs(res[k][1]["rssi_db"] - m_ref["rssi_db"]) <= 2e-4
+                assert db_close(res[k][1]["rssi_db"], m_ref["rssi_db"])
 
 
 def test_chain_nbfm_single_channel_dropin(wh, golden):
@@ -177,26 +177,26 @@ def test_n1_signal_metrics(wh, golden, O):
     offs = S.nbfm_bank_offsets()
     res = wh.update_signal_metrics(iq, fs, offs)
     for row, k in zip(g["sigmet"], (0, 13, 31)):
-        assert abs(res[k]["rssi_db"] - row[0]) <= 2e-4 and abs(res[k]["snr_db"] - row[1]) <= 2e-4
+        assert db_close(res[k]["rssi_db"], row[0]) and db_close(res[k]["snr_db"], row[1])
     for k in (5, 20):
         rssi, snr = O.update_signal_metrics(iq, fs, offs[k])
-        assert abs(res[k]["rssi_db"] - rssi) <= 2e-4 and abs(res[k]["snr_db"] - snr) <= 2e-4
+        assert db_close(res[k]["rssi_db"], rssi) and db_close(res[k]["snr_db"], snr)
     # int16 input and a zero offset (no mix)
     i16 = S.pack_iq16_np(iq)
     r2 = wh.update_signal_metrics(i16, fs, [0.0, offs[3]], input_format="int16")
     z = O.unpack_iq16(i16)
     for got, off in zip(r2, (0.0, offs[3])):
         rssi, snr = O.update_signal_metrics(z, fs, off)
-        assert abs(got["rssi_db"] - rssi) <= 2e-4 and abs(got["snr_db"] - snr) <= 2e-4
+        assert db_close(got["rssi_db"], rssi) and db_close(got["snr_db"], snr)
     # one ranking of |iq| for all channels (no mix: |freq_shift(iq)| = |iq| up to float32 rounding) against the
     # reference goldens of three channels, and through the dispatcher (one upload, snr_db on every channel)
     sh = wh.update_signal_metrics(iq, fs, offs, shared_magnitudes=True)
     for row, k in zip(g["sigmet"], (0, 13, 31)):
-        assert abs(sh[k]["rssi_db"] - row[0]) <= 2e-4 and abs(sh[k]["snr_db"] - row[1]) <= 2e-4
+        assert db_close(sh[k]["rssi_db"], row[0]) and db_close(sh[k]["snr_db"], row[1])
     cfgs = [wh.ChannelConfig(mode="nbfm", offset_hz=offs[k], enable_deemphasis=False) for k in (0, 13, 31)]
     out = wh.ChannelDispatcher(fs).process(iq, cfgs, snr=True)
     for (audio, m), row in zip(out, g["sigmet"]):
-        assert audio is not None and abs(m["rssi_db"] - row[0]) <= 2e-4 and abs(m["snr_db"] - row[1]) <= 2e-4
+        assert audio is not None and db_close(m["rssi_db"], row[0]) and db_close(m["snr_db"], row[1])
 
 
 def test_chain_wbfm(wh, golden):
@@ -207,7 +207,7 @@ def test_chain_wbfm(wh, golden):
         cfg = wh.ChannelConfig(id="w", mode="wbfm", offset_hz=float(off))
         audio, met = wh.process_channel_dsp_stateless(iq, fs, cfg)
         assert peak_rel_err(audio, g[f"wbfm{ci}_audio"]) <= TOL
-        assert np.allclose([met["rssi_db"], met["signal_power_db"]], g[f"wbfm{ci}_met"], atol=2e-4)
+        assert db_close([met["rssi_db"], met["signal_power_db"]], g[f"wbfm{ci}_met"])
 
 
 def test_chain_am_ssb_filtered_fm(wh, golden, O):
@@ -232,7 +232,7 @@ def test_chain_am_ssb_filtered_fm(wh, golden, O):
         audio, met = wh.process_channel_dsp_stateless(iq, fs, cfgs[tag])
         assert audio is not None and audio.shape == g[f"{tag}_audio"].shape, tag
         assert peak_rel_err(audio, g[f"{tag}_audio"]) <= TOL, tag
-        assert np.allclose([met["rssi_db"], met["signal_power_db"]], g[f"{tag}_met"], atol=2e-4), tag
+        assert db_close([met["rssi_db"], met["signal_power_db"]], g[f"{tag}_met"]), tag
     # a bank of 3 AM channels on one chunk vs the oracle
     fs, n = 48000, 4800
     iq = (S.am_tone_c64(n, fs, 61, carrier_hz=3000.0) + S.am_tone_c64(n, fs, 62, carrier_hz=-7000.0, audio_hz=500.0)
@@ -435,9 +435,16 @@ def test_a13_channel_stats(wh, O):
     y = ch.process_device(torch.from_numpy(x).cuda())
     st = ch.channel_stats_device(y).cpu().numpy()
     ref = O.pfb_channel_stats(y.cpu().numpy())
-    assert np.allclose(st, ref, rtol=1e-9, atol=0)
+    # the statistic's definition: p in float32 (count, min, max exact), sums of short float32 blocks in float64 (<= 2e-6)
+    assert np.array_equal(st[:, 2:], ref[:, 2:])
+    assert np.allclose(st[:, :2], ref[:, :2], rtol=2e-6, atol=0)
+    record_margin(float(np.max(np.abs(st[:, :2] - ref[:, :2]) / ref[:, :2])), tol=2e-6)
     st2 = ch.channel_stats_device(y, torch.from_numpy(st.copy()).cuda(), accumulate=True).cpu().numpy()
-    assert np.allclose(st2[:, :3], 2 * ref[:, :3], rtol=1e-9) and np.allclose(st2[:, 3:], ref[:, 3:], rtol=1e-12)
+    assert np.allclose(st2[:, :2], 2 * st[:, :2], rtol=1e-15) and np.array_equal(st2[:, 2], 2 * ref[:, 2])
+    assert np.array_equal(st2[:, 3:], ref[:, 3:])
+    # accumulate into an EMPTY row (count 0, e.g. a zero-initialised buffer) == overwrite: its zeros are no observations
+    st3 = ch.channel_stats_device(y, torch.zeros_like(torch.from_numpy(st)).cuda(), accumulate=True).cpu().numpy()
+    assert np.array_equal(st3, st)
 
 
 def test_a4_a5_trunking_ddc(wh, golden, O):
@@ -473,7 +480,7 @@ def test_a13_scanner_measure(wh, golden, O):
     res = wh.ScannerMeasure(fs).measure(w, [float(v) for v in g["scan_offsets"]])
     got = np.array([[m["power_db"], m["peak_power_db"], m["noise_floor_db"], m["snr_db"], m["sample_count"]]
                     for m in res])
-    assert np.allclose(got[:, :4], g["scan_meas"][:, :4], atol=2e-4)
+    assert db_close(got[:, :4], g["scan_meas"][:, :4])
     assert np.array_equal(got[:, 4], g["scan_meas"][:, 4])
     order = np.argsort(-got[:, 3])
     assert order[0] == 0 and order[1] == 1            # the two carriers rank first by SNR
@@ -484,7 +491,7 @@ def test_a13_scanner_measure(wh, golden, O):
     res2 = wh.ScannerMeasure(fs).measure(w2, offs)
     ref2 = O.scanner_measure(w2, fs, offs, sync_check=True)
     got2 = np.array([[m["power_db"], m["peak_power_db"], m["noise_floor_db"], m["snr_db"]] for m in res2])
-    assert np.allclose(got2, g["scan2_meas"][:, :4], atol=2e-4)
+    assert db_close(got2, g["scan2_meas"][:, :4])
     assert [float(m["sync_detected"]) for m in res2] == list(g["scan2_meas"][:, 4])
     for a, b in zip(res2, ref2):
         assert abs(a["sync_correlation"] - b["sync_correlation"]) <= 1e-6
@@ -540,13 +547,13 @@ def test_chain_raw_and_digital_modes(wh, golden):
         audio, met = wh.process_channel_dsp_stateless(iq, fs, wh.ChannelConfig(mode="raw", offset_hz=float(off)))
         assert audio.dtype == np.float32 and audio.shape == (2 * n,)
         assert peak_rel_err(audio, g[f"raw{ci}_audio"]) <= TOL
-        assert np.abs(np.array([met["rssi_db"], met["signal_power_db"]]) - g[f"raw{ci}_met"]).max() <= 2e-4
+        assert db_close([met["rssi_db"], met["signal_power_db"]], g[f"raw{ci}_met"])
         for mode in ("p25", "dmr", "nxdn", "dstar", "ysf"):
             audio, met = wh.process_channel_dsp_stateless(iq, fs, wh.ChannelConfig(mode=mode, offset_hz=float(off)))
             assert audio is None
-            assert np.abs(np.array([met["rssi_db"], met["signal_power_db"]]) - g[f"dig{ci}_met"]).max() <= 2e-4
+            assert db_close([met["rssi_db"], met["signal_power_db"]], g[f"dig{ci}_met"])
     audio, met = wh.process_channel_dsp_stateless((iq * 40).astype(np.complex64), fs, wh.ChannelConfig(mode="raw"))
-    assert audio is None and "signal_power_db" not in met and abs(met["rssi_db"] - float(g["loud_rssi"])) <= 2e-4
+    assert audio is None and "signal_power_db" not in met and db_close(met["rssi_db"], float(g["loud_rssi"]))
     bad = iq.copy()
     bad[5] = np.nan
     assert wh.process_channel_dsp_stateless(bad, fs, wh.ChannelConfig(mode="raw")) == (None, {})
@@ -562,12 +569,51 @@ def test_chain_sam(wh, golden):
         audio, met = wh.process_channel_dsp_stateless(iq, fs, cfg)
         assert audio is not None and audio.shape == g[f"{tag}_audio"].shape, tag
         assert peak_rel_err(audio, g[f"{tag}_audio"]) <= TOL, tag
-        assert np.abs(np.array([met["rssi_db"], met["signal_power_db"]]) - g[f"{tag}_met"]).max() <= 2e-4, tag
+        assert db_close([met["rssi_db"], met["signal_power_db"]], g[f"{tag}_met"]), tag
     tag, fs, iq, off, kw = next(sam_cases(g))
     cfgs = [wh.ChannelConfig(mode="sam", offset_hz=o, **kw) for o in (off - 50.0, off, off + 50.0)]
     res = wh.ChannelBank(fs, iq.shape[0], cfgs).process(iq)
     assert peak_rel_err(res[1][0], g[f"{tag}_audio"]) <= TOL
     assert res[0][0] is not None and res[2][0] is not None
+
+
+def test_chain_am_ssb_sam_at_capture_rates(wh, golden):
+    """AM / SSB / SAM where the live loop runs them: 250 kS/s and 2.4 MS/s chunks (`chain_caprate`, from the reference).
+    The reference's order-5 ba-form Butterworths are ill-conditioned at these rates (a +-1-ulp input perturbation moves
+    the AM audio by 4e-4 at 250 kS/s and by 0.4 at 2.4 MS/s; the SSB band-pass overflows), so what the goldens pin is what
+    the live loop acts on (capture.py:323-325, 2593-2595): the OUTCOME CLASS -- audio, or None because
+    validate_audio_samples fails (validation.py:41-52) -- and the metrics; the audio itself wherever the measured
+    sensitivity `sens` is below 1e-3, to max(1e-5, 4 * sens); signal_power_db to max(2e-4 dB, 4 x the shift the same
+    perturbation gives the reference's own value)."""
+    import ast
+    g = golden("chain_caprate")
+    n_audio = 0
+    for tag in [str(t) for t in g["tags"]]:
+        fs, n, seed, car, off = g[f"{tag}_args"]
+        iq = S.am_tone_c64(int(n), int(fs), seed=int(seed), carrier_hz=float(car), depth=0.7)
+        assert S.sha256(iq) == str(g[f"{tag}_sha"])
+        kw = ast.literal_eval(str(g[f"{tag}_kw"]))
+        cfg = wh.ChannelConfig(mode=str(g[f"{tag}_mode"]), offset_hz=float(off), **kw)
+        audio, met = wh.process_channel_dsp_stateless(iq, int(fs), cfg)
+        want_audio = bool(int(g[f"{tag}_class"]))
+        assert (audio is not None) == want_audio, (tag, "outcome class")
+        ref_met, ref_pert = g[f"{tag}_met"], g[f"{tag}_met_pert"]
+        assert db_close(met["rssi_db"], ref_met[0], label="rssi dB"), tag
+        assert ("signal_power_db" in met) == want_audio, tag
+        if not want_audio:
+            continue
+        sens = float(g[f"{tag}_sens"])
+        sp_tol = max(2e-4, 4.0 * abs(float(ref_met[1] - ref_pert[1])))
+        assert db_close(met["signal_power_db"], ref_met[1], tol=sp_tol,
+                        label="signal power dB" if sp_tol == 2e-4 else "signal power dB (ill-conditioned)"), (tag, sp_tol)
+        assert audio.shape == g[f"{tag}_audio"].shape, tag
+        if sens < 1e-3:
+            tol = max(TOL, 4.0 * sens)
+            err = float(np.max(np.abs(audio - g[f"{tag}_audio"])) / np.max(np.abs(g[f"{tag}_audio"])))
+            record_margin(err, tol, "audio" if tol == TOL else "audio at 4 x measured sensitivity")
+            assert err <= tol, (tag, err, tol)
+            n_audio += 1
+    assert n_audio >= 5
 
 
 def test_chain_spectral_noise_reduction(wh, golden):
@@ -590,8 +636,9 @@ def test_chain_spectral_noise_reduction(wh, golden):
         assert audio is not None and audio.shape == g[f"{tag}_audio"].shape, (tag, None if audio is None else audio.shape)
         ref = g[f"{tag}_audio"]
         err = np.abs(audio - ref) / np.max(np.abs(ref))
+        record_margin(err[8:-8].max(), TOL, 'interior'); record_margin(err.max(), 1e-3, '8 samples next to a row edge')
         assert err[8:-8].max() <= TOL and err.max() <= 1e-3, (tag, err[8:-8].max(), err.max())
-        assert np.abs(np.array([met["rssi_db"], met["signal_power_db"]]) - g[f"{tag}_met"]).max() <= 2e-4, tag
+        assert db_close([met["rssi_db"], met["signal_power_db"]], g[f"{tag}_met"]), tag
 
 
 def test_n1_squelch_in_bank(wh):
@@ -816,7 +863,7 @@ def test_n1_channel_dispatcher_mixed_modes(wh, golden):
     assert len(res) == len(cfgs) and len(disp._banks) == 3
     for k, i in ((0, 0), (13, 2), (31, 5)):
         assert peak_rel_err(res[i][0], g[f"nbfm0_k{k}_audio"]) <= TOL
-        assert np.abs(np.array([res[i][1]["rssi_db"], res[i][1]["signal_power_db"]]) - g[f"nbfm0_k{k}_met"]).max() <= 2e-4
+        assert db_close([res[i][1]["rssi_db"], res[i][1]["signal_power_db"]], g[f"nbfm0_k{k}_met"])
     for i, c in enumerate(cfgs):
         a, m = wh.process_channel_dsp_stateless(iq, fs, c)
         if a is None:
@@ -876,7 +923,7 @@ def test_chain_nbfm_other_rates_vs_oracle(wh, O):
                 ref, met = O.process_channel_nbfm(z, fs, o)
                 assert res[k][0].shape == ref.shape, (fs, k)
                 assert peak_rel_err(res[k][0], ref) <= TOL, (fs, fmt, k, peak_rel_err(res[k][0], ref))
-                assert abs(res[k][1]["rssi_db"] - met["rssi_db"]) <= 2e-4
+                assert db_close(res[k][1]["rssi_db"], met["rssi_db"])
 
 
 def test_a14_noise_blanker(wh, golden):
@@ -902,7 +949,7 @@ def test_chain_small_and_odd_chunk_lengths(wh, O):
         a, m = wh.process_channel_dsp_stateless(iq, fs, wh.ChannelConfig(mode="wbfm", offset_hz=100e3))
         ref, met = O.process_channel_wbfm(iq, fs, 100e3)
         assert a.shape == ref.shape and peak_rel_err(a, ref) <= TOL, ("wbfm", n, peak_rel_err(a, ref))
-        assert abs(m["rssi_db"] - met["rssi_db"]) <= 2e-4
+        assert db_close(m["rssi_db"], met["rssi_db"])
 
 
 @pytest.mark.parametrize("fs,bw,M", [(8_000_000, 25_000, 320), (2_400_000, 12_500, 192), (6_000_000, 12_500, 480),
@@ -1064,8 +1111,10 @@ def test_a7_pfb_prefetch_forms_agree(wh):
 def test_a13_statistics_only_filterbank(wh, M):
     """wh_pfb_run_stats: the filterbank in statistics-only mode (last pass reduces |y|^2 in registers, no channel outputs
     written) == wh_pfb_channel_stats over the full output of the same input: {sum, sum of squares, count, min, max} per
-    channel to 1e-12 relative (sums are added in another order), history carried identically, two calls accumulate, int16
-    input; a channel count without a shaped kernel is refused."""
+    channel: count, min and max EXACTLY (both take p = float32(float32(re^2) + float32(im^2)) of bit-identical outputs), the
+    two sums to 2e-6 relative (float32 block sums added in float64; the grouping into blocks differs between the
+    kernels and is not part of the definition); history carried identically, two calls accumulate, int16 input; a channel
+    count without a shaped kernel is refused."""
     import torch
 
     fs, bw = M * 25_000, 25_000
@@ -1084,13 +1133,15 @@ def test_a13_statistics_only_filterbank(wh, M):
         got = st.process_stats_device(x[lo:hi], got, accumulate=got is not None)
         assert np.array_equal(full.arm_history, st.arm_history)
     r, s = ref.cpu().numpy(), got.cpu().numpy()
-    assert np.array_equal(r[:, 2], s[:, 2])
-    assert np.max(np.abs(r - s) / np.maximum(np.abs(r), 1e-300)) <= 1e-12, np.max(np.abs(r - s) / np.maximum(np.abs(r), 1e-300))
+    assert np.array_equal(r[:, 2:], s[:, 2:])
+    err = float(np.max(np.abs(r[:, :2] - s[:, :2]) / r[:, :2]))
+    record_margin(err, tol=2e-6)
+    assert err <= 2e-6, err
     i16 = torch.from_numpy(S.pack_iq16_np(x[:n1].cpu().numpy())).cuda()
     a, b = wh.PolyphaseChannelizer(fs, bw).tune(path="shaped"), wh.PolyphaseChannelizer(fs, bw)
     r16 = a.channel_stats_device(a.process_device(i16)).cpu().numpy()
     s16 = b.process_stats_device(i16).cpu().numpy()
-    assert np.max(np.abs(r16 - s16) / np.maximum(np.abs(r16), 1e-300)) <= 1e-12
+    assert np.array_equal(r16[:, 2:], s16[:, 2:]) and np.max(np.abs(r16[:, :2] - s16[:, :2]) / r16[:, :2]) <= 2e-6
     if M == 320:
         odd = wh.PolyphaseChannelizer(2_800_000, 100_000)      # M = 28: no shaped kernel
         with pytest.raises(RuntimeError):

@@ -3,13 +3,15 @@
 the prefetch loads or the passes suppressed.  pfb_mid_ablate.py [FS BW [LOG2N]]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "wavecap-sdr_amd")]
+sys.path[:0] = [ROOT, os.environ.get("WAVEHIP_PKG_DIR", os.path.join(ROOT, "wavecap-sdr_amd"))]   # WAVEHIP_PKG_DIR: a DIAG build elsewhere
 import torch, wavehip
 from wavehip import _lib
 fs, bw = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (8_000_000, 25_000)
 logn = int(sys.argv[3]) if len(sys.argv) > 3 else 26
 n = 1 << logn
 ch = wavehip.PolyphaseChannelizer(fs, bw)
+if ch.channel_count == 1024:
+    ch.tune(path="shaped")      # the 1024-channel default is the tuned kernel; the ablation bits live in the shaped one
 x = torch.view_as_complex(torch.randn(n, 2, device="cuda").mul_(0.5))
 out = torch.empty((ch.hops(n), ch.channel_count), dtype=torch.complex64, device="cuda")
 for rep in range(2):

@@ -1,8 +1,17 @@
 #!/bin/bash
 # pmc_run.sh OUTDIR -- python3 script args...   : kernel trace + three SQ passes + FETCH / WRITE passes, each its own
 # rocprofv3 run (counters never combined with other trace domains), then the per-kernel summary.
+# The profiler's preload initialises the GPU before the program starts, and bench.py's cpu_baseline forks worker
+# processes: a bench.py target is therefore always run with --no-cpu (appended here when missing).
 set -e
+if [ "$#" -lt 3 ] || [ "$2" != "--" ]; then
+    echo "usage: pmc_run.sh OUTDIR -- python3 script args..." >&2
+    exit 2
+fi
 OUT=$1; shift; shift
+case " $* " in
+    *bench.py*) case " $* " in *" --no-cpu "*) ;; *) set -- "$@" --no-cpu ;; esac ;;
+esac
 export TMPDIR=/tmp
 mkdir -p "$OUT"
 rocprofv3 --kernel-trace --stats -d "$OUT/trace" --output-format csv -- "$@" ${TRACE_EXTRA} > "$OUT/trace.log" 2>&1

@@ -743,15 +743,23 @@ __global__ void pfb_stats_kernel(const float2 *out, size_t hops, int M, double *
     int sl = blockIdx.y;
     size_t per = (hops + slices - 1) / slices;
     size_t h0 = (size_t)sl * per, h1 = h0 + per < hops ? h0 + per : hops;
-    double s = 0, s2 = 0, mn = 1e300, mx = -1e300;
+    // the statistic's definition (see StAcc in pfb_mid.hip): p = float32(float32(re^2) + float32(im^2)); sum p and
+    // sum p^2 in float32 over blocks of <= 16 of the thread's hops, the block sums added in float64; min / max exact
+    double s = 0, s2 = 0, mn = INFINITY, mx = -INFINITY;
     if (c < M) {
+        float fs = 0.f, fs2 = 0.f, fmn = INFINITY, fmx = -INFINITY;
+        int open = 0;
         for (size_t h = h0 + threadIdx.y; h < h1; h += blockDim.y) {
-            float2 v = out[h * M + c];
-            double p = (double)v.x * v.x + (double)v.y * v.y;
-            s += p; s2 += p * p;
-            mn = p < mn ? p : mn;
-            mx = p > mx ? p : mx;
+            const float2 v = out[h * M + c];
+            const float p = __fadd_rn(__fmul_rn(v.x, v.x), __fmul_rn(v.y, v.y));
+            fs = __fadd_rn(fs, p);
+            fs2 = fmaf(p, p, fs2);
+            fmn = fminf(fmn, p);
+            fmx = fmaxf(fmx, p);
+            if (++open == 16) { s += (double)fs; s2 += (double)fs2; fs = 0.f; fs2 = 0.f; open = 0; }
         }
+        s += (double)fs; s2 += (double)fs2;
+        mn = (double)fmn; mx = (double)fmx;
     }
     __shared__ double red[4][4][64];
     red[0][threadIdx.y][threadIdx.x] = s;
@@ -777,7 +785,7 @@ __global__ __launch_bounds__(256) void pfb_stats_final_kernel(const double *part
                                                              double *stats, int accumulate) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), sl = threadIdx.x & 63;
     if (c >= M) return;
-    double s = 0, s2 = 0, mn = 1e300, mx = -1e300;
+    double s = 0, s2 = 0, mn = INFINITY, mx = -INFINITY;
     if (sl < slices) {
         const double *p = part + ((size_t)sl * M + c) * 4;
         s = p[0]; s2 = p[1]; mn = p[2]; mx = p[3];
@@ -790,7 +798,9 @@ __global__ __launch_bounds__(256) void pfb_stats_final_kernel(const double *part
     }
     if (sl != 0) return;
     double *o = stats + (size_t)c * 5;
-    if (accumulate) {
+    // accumulate into a row that holds nothing yet (count 0 -- e.g. a zero-initialised buffer) == overwrite: its min / max
+    // fields are not observations.  An empty row reads {0, 0, 0, +inf, -inf} (the convention of wh_binstats_update too).
+    if (accumulate && o[2] > 0.0) {
         o[0] += s; o[1] += s2; o[2] += (double)hops;
         o[3] = fmin(o[3], mn); o[4] = fmax(o[4], mx);
     } else {
@@ -802,11 +812,11 @@ __global__ __launch_bounds__(256) void pfb_stats_final_kernel(const double *part
 __global__ void stats_merge_kernel(const double *g, int R, int M, double *out) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= M) return;
-    double s0 = 0, s1 = 0, s2 = 0, mn = 1e300, mx = -1e300;
+    double s0 = 0, s1 = 0, s2 = 0, mn = INFINITY, mx = -INFINITY;   // no observation anywhere: {0, 0, 0, +inf, -inf}
     for (int r = 0; r < R; ++r) {
         const double *p = g + ((size_t)r * M + c) * 5;
         s0 += p[0]; s1 += p[1]; s2 += p[2];
-        mn = fmin(mn, p[3]); mx = fmax(mx, p[4]);
+        if (p[2] > 0.0) { mn = fmin(mn, p[3]); mx = fmax(mx, p[4]); }   // a rank without hops contributes no min / max
     }
     double *o = out + (size_t)c * 5;
     o[0] = s0; o[1] = s1; o[2] = s2; o[3] = mn; o[4] = mx;
@@ -1027,7 +1037,7 @@ static int pfb_run_fmt(wh_pfb *p, const void *d_iq, int fmt, size_t n, float *d_
         c.x = d_iq; c.fmt = fmt; c.n = n;
         c.hist = p->d_hist[p->cur]; c.new_hist = p->d_hist[p->cur ^ 1];
         c.out = reinterpret_cast<float2 *>(d_out);
-        c.sink = p->d_sink;
+        c.sink = p->d_sink; c.sink_elems = (size_t)p->M;
         c.arms = p->d_arms; c.tw = p->d_tw;
         c.H = H; c.cu_count = p->cu_count; c.hops_per_run = p->gpw_override; c.stats_only = 0;
         c.stats_ws = nullptr; c.stats_out = nullptr; c.stats_accumulate = 0;
@@ -1257,7 +1267,7 @@ extern "C" int wh_pfb_run_stats(wh_pfb *p, const void *d_iq, int input_format, s
     PfbMidCall c;
     c.x = d_iq; c.fmt = input_format; c.n = n;
     c.hist = p->d_hist[p->cur]; c.new_hist = p->d_hist[p->cur ^ 1];
-    c.out = nullptr; c.sink = p->d_sink;
+    c.out = nullptr; c.sink = p->d_sink; c.sink_elems = (size_t)p->M;
     c.arms = p->d_arms; c.tw = p->d_tw;
     c.H = H; c.cu_count = p->cu_count; c.hops_per_run = p->gpw_override;
     c.stats_only = 1; c.stats_ws = nullptr; c.stats_out = d_stats; c.stats_accumulate = accumulate;

@@ -12,7 +12,8 @@ struct PfbMidCall {
     const float2 *hist;      // [M][T] carried history (column j = block_{-1-j}); read
     float2 *new_hist;        // [M][T] history after this call; written
     float2 *out;             // [H][M]
-    float2 *sink;            // [M] scratch row nobody reads (stores of hops past the end of the call)
+    float2 *sink;            // [sink_elems >= M] scratch row nobody reads (stores of hops past the end of the call)
+    size_t sink_elems;       // checked at launch: a sink smaller than a row would put those stores outside any allocation
     const float *arms;       // float32 [M][T]
     const float2 *tw;        // exp(-2 pi i m / M), m in [0, M)
     long long H;             // hops of this call (> 0)
@@ -35,7 +36,8 @@ struct SpectrumMidCall {
     size_t frame_stride;
     long long n_frames;      // > 0
     float *out;              // [n_frames][N] dB
-    float *sink;             // [N] scratch row nobody reads
+    float *sink;             // [sink_elems >= N] scratch row nobody reads
+    size_t sink_elems;
     const float *window;     // [N]
     const float2 *tw;        // exp(-2 pi i m / N)
     int cu_count;

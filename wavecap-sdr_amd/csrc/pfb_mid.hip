@@ -462,11 +462,39 @@ __device__ __forceinline__ void mid_last_units(const v2f *img, v2f *out, v2f *si
     }
 }
 
-// last pass in statistics-only mode: same butterflies, outputs reduced into the lane's accumulators (p = re^2 + im^2 in
-// float64, as wh_pfb_channel_stats computes it) instead of stored.  Units chunk-major: ui = c S_NHG + hg.
+// Activity statistic of a channel (A13; the repo's own definition, consumed by the scanner / classifier as dB levels):
+// p = float32(float32(re^2) + float32(im^2)) of every output; {sum p, sum p^2} are taken in float32 over short blocks of
+// hops (at most 16 of a lane's consecutive visits) and the block sums added in float64; min / max are exact float32.
+// Both producers (this kernel and wh_pfb_channel_stats over a stored output) compute the same p bit for bit, so count,
+// min and max agree exactly; the sums agree to the float32 block rounding (<= 2e-6 relative, typically 2e-7): the
+// grouping into blocks is the kernel's business and not part of the definition.  (Round 2 took p, p^2 and the four
+// reductions in float64: 16 issue slots per output against ~5 here, which made the statistics-only pass -- no stores
+// at all -- slower than the pass that writes 4.3 GB.)
+struct StAcc {
+    double s, s2;          // float64 sums of the folded blocks
+    float fs, fs2, mn, mx; // open block (float32), exact extremes
+};
+__device__ __forceinline__ void stacc_init(StAcc &a) { a.s = 0.0; a.s2 = 0.0; a.fs = 0.f; a.fs2 = 0.f; a.mn = INFINITY; a.mx = 0.f; }
+__device__ __forceinline__ void stacc_fold(StAcc &a) {
+    a.s += (double)a.fs; a.s2 += (double)a.fs2;
+    a.fs = 0.f; a.fs2 = 0.f;
+}
+__device__ __forceinline__ float stat_power(v2f y) {
+    const v2f sq = y * y;                  // one packed multiply: (re^2, im^2), each rounded
+    return __fadd_rn(sq.x, sq.y);          // no contraction into an FMA: the stored-output kernel must get the same bits
+}
+__device__ __forceinline__ void stacc_add(StAcc &a, float pw) {
+    a.fs = __fadd_rn(a.fs, pw);
+    a.fs2 = fmaf(pw, pw, a.fs2);
+    a.mn = fminf(a.mn, pw);
+    a.mx = fmaxf(a.mx, pw);
+}
+
+// last pass in statistics-only mode: same butterflies, outputs reduced into the lane's accumulators instead of stored.
+// Units chunk-major: ui = c S_NHG + hg.
 template <class C>
 __device__ __forceinline__ void mid_last_stats(const v2f *img, int lane, int wave, long long hop0, int stride_r,
-                                               long long limit, double (&acc)[C::NACC][4]) {
+                                               long long limit, StAcc (&acc)[C::NACC]) {
     constexpr int r = C::RL, LSU = C::LSU, HR = C::S_HR, NHG = C::S_NHG, UPW = C::S_UPW;
     const int hs = HR == 1 ? 0 : lane / LSU, kl = lane - hs * LSU;
     const v2f *base = img + hs * C::IMGS + C::ph(C::pos_of(kl));
@@ -484,14 +512,7 @@ __device__ __forceinline__ void mid_last_stats(const v2f *img, int lane, int wav
         bfly(v);
         if (hop < limit) {
 #pragma unroll
-            for (int k = 0; k < r; ++k) {
-                const double p = (double)v[k].x * (double)v[k].x + (double)v[k].y * (double)v[k].y;
-                double (&a4)[4] = acc[ci * r + k];
-                a4[0] += p;
-                a4[1] += p * p;
-                a4[2] = fmin(a4[2], p);
-                a4[3] = fmax(a4[3], p);
-            }
+            for (int k = 0; k < r; ++k) stacc_add(acc[ci * r + k], stat_power(v[k]));
         }
     }
 }
@@ -502,7 +523,7 @@ __device__ __forceinline__ void mid_last_stats(const v2f *img, int lane, int wav
 template <class C, bool STATS = false>
 __device__ __forceinline__ void mid_transform(v2f *img, const v4f *twp, v2f *out, v2f *sink, int tid, int wave,
                                               long long hop_g, int stride_r, long long limit,
-                                              double (*acc)[4] = nullptr) {
+                                              StAcc *acc = nullptr) {
     // opaque copy of the thread index: the image / twiddle / output offsets of the passes are loop invariant and would
     // otherwise be hoisted out of the group loop and parked in registers for the whole run
     int lt = C::WAVE_MODE ? (tid & 63) : tid;
@@ -516,7 +537,7 @@ __device__ __forceinline__ void mid_transform(v2f *img, const v4f *twp, v2f *out
     } else {
         mid_passes_affine<C, 0, C::TH, C::NIMG, true>(img, twp, lt);
         if constexpr (STATS) mid_last_stats<C>(img, lt & 63, wave, hop_g, stride_r, limit,
-                                               *reinterpret_cast<double (*)[C::NACC][4]>(acc));
+                                               *reinterpret_cast<StAcc (*)[C::NACC]>(acc));
         else if constexpr (C::LSU > 0) mid_last_units<C>(img, out, sink, lt & 63, wave, hop_g, stride_r, limit);
         else mid_last_generic<C, C::NTL, C::NIMG>(img, out, sink, lt, 0, hop_g, stride_r, limit);
     }
@@ -591,7 +612,7 @@ __device__ __forceinline__ void mid_mac_group(const MidArgs &a, v2f (&wA)[C::T +
 
 // the workgroup's accumulators -> [M][4] float64 in LDS (the image memory, free by now) -> its row of the workspace
 template <class C>
-__device__ __forceinline__ void mid_stats_flush(v2f *img, double (&acc)[C::NACC][4], double *ws_row, int tid, int wave) {
+__device__ __forceinline__ void mid_stats_flush(v2f *img, StAcc (&acc)[C::NACC], double *ws_row, int tid, int wave) {
     constexpr int M = C::M, r = C::RL, LSU = C::LSU, NHG = C::S_NHG, UPW = C::S_UPW;
     double *stg = reinterpret_cast<double *>(img);                       // [4][M]: sum, sum^2, min, max
     unsigned long long *stgu = reinterpret_cast<unsigned long long *>(img);
@@ -612,11 +633,12 @@ __device__ __forceinline__ void mid_stats_flush(v2f *img, double (&acc)[C::NACC]
 #pragma unroll
         for (int k = 0; k < r; ++k) {
             const int ch = kl + LSU * c + k * C::BPL;
-            const double (&a4)[4] = acc[ci * r + k];
-            atomicAdd(&stg[ch], a4[0]);
-            atomicAdd(&stg[M + ch], a4[1]);
-            atomicMin(&stgu[2 * M + ch], (unsigned long long)__double_as_longlong(a4[2]));   // p >= 0: bit patterns order like values
-            atomicMax(&stgu[3 * M + ch], (unsigned long long)__double_as_longlong(a4[3]));
+            StAcc &a4 = acc[ci * r + k];
+            stacc_fold(a4);
+            atomicAdd(&stg[ch], a4.s);
+            atomicAdd(&stg[M + ch], a4.s2);
+            atomicMin(&stgu[2 * M + ch], (unsigned long long)__double_as_longlong((double)a4.mn));   // p >= 0: bit patterns order like values
+            atomicMax(&stgu[3 * M + ch], (unsigned long long)__double_as_longlong((double)a4.mx));
         }
     }
     __syncthreads();
@@ -640,11 +662,13 @@ void pfb_mid_kernel(MidArgs a) {
 
     const int tid = threadIdx.x;
     const int bid = blockIdx.x;
-    double acc[STATS ? C::NACC : 1][4];
+    StAcc acc[STATS ? C::NACC : 1];
     if (STATS) {
 #pragma unroll
-        for (int i = 0; i < C::NACC; ++i) { acc[i][0] = 0.0; acc[i][1] = 0.0; acc[i][2] = __longlong_as_double(0x7ff0000000000000LL); acc[i][3] = 0.0; }
+        for (int i = 0; i < C::NACC; ++i) stacc_init(acc[i]);
     }
+    // a lane visits a channel S_NHG times per group: its open float32 block is folded after at most 16 visits
+    constexpr int FOLD_G = C::S_NHG >= 16 ? 1 : 16 / (C::S_NHG > 0 ? C::S_NHG : 1);
 
     if (bid == a.n_head) {   // history for the next call: new_hist[k][j] = block_{H-1-j}[k]
         for (int idx = tid; idx < M * T; idx += NT) {
@@ -715,8 +739,7 @@ void pfb_mid_kernel(MidArgs a) {
         }
         __syncthreads();   // images and twiddle tables
         mid_transform<C, STATS>(img, twp, a.out, a.sink, tid, wave, hop_base, GH, limit, acc);
-        if constexpr (STATS) mid_stats_flush<C>(img, *reinterpret_cast<double (*)[C::NACC][4]>(acc),
-                                                a.stats_ws + (size_t)bid * 4 * M, tid, wave);
+        if constexpr (STATS) mid_stats_flush<C>(img, acc, a.stats_ws + (size_t)bid * 4 * M, tid, wave);
         return;
     }
 
@@ -779,12 +802,17 @@ void pfb_mid_kernel(MidArgs a) {
         else __syncthreads();
         WH_STAMP(2)
         if (passes) mid_transform<C, STATS>(img, twp, a.out, a.sink, tid, wave, hop_g, a.hpr, limit, acc);
+        if constexpr (STATS) {
+            if ((g + 1) % FOLD_G == 0) {
+#pragma unroll
+                for (int i = 0; i < C::NACC; ++i) stacc_fold(acc[i]);
+            }
+        }
         WH_STAMP(3)
         if (C::SELF) __builtin_amdgcn_wave_barrier();
         else __syncthreads();
     }
-    if constexpr (STATS) mid_stats_flush<C>(img, *reinterpret_cast<double (*)[C::NACC][4]>(acc),
-                                            a.stats_ws + (size_t)bid * 4 * M, tid, wave);
+    if constexpr (STATS) mid_stats_flush<C>(img, acc, a.stats_ws + (size_t)bid * 4 * M, tid, wave);
 }
 
 // statistics-only mode, second step: the workgroups' rows [rows][4][M] -> d_stats [M][5] = {sum p, sum p^2, hops, min, max}
@@ -792,7 +820,7 @@ void pfb_mid_kernel(MidArgs a) {
 __global__ __launch_bounds__(1024) void mid_stats_reduce_kernel(const double *ws, int rows, int skip, int M, double hops,
                                                                double *stats, int accumulate) {
     const int c = blockIdx.x * 64 + threadIdx.x, y = threadIdx.y;
-    double s = 0, s2 = 0, mn = 1e300, mx = 0;
+    double s = 0, s2 = 0, mn = INFINITY, mx = -INFINITY;
     if (c < M)
         for (int r = y; r < rows; r += 16) {
             if (r == skip) continue;
@@ -809,7 +837,8 @@ __global__ __launch_bounds__(1024) void mid_stats_reduce_kernel(const double *ws
             mn = fmin(mn, red[2][k][threadIdx.x]); mx = fmax(mx, red[3][k][threadIdx.x]);
         }
         double *o = stats + (size_t)c * 5;
-        if (accumulate) { o[0] += s; o[1] += s2; o[2] += hops; o[3] = fmin(o[3], mn); o[4] = fmax(o[4], mx); }
+        // (a row with count 0 holds no observation: accumulate == overwrite, as in pfb_stats_final_kernel)
+        if (accumulate && o[2] > 0.0) { o[0] += s; o[1] += s2; o[2] += hops; o[3] = fmin(o[3], mn); o[4] = fmax(o[4], mx); }
         else { o[0] = s; o[1] = s2; o[2] = hops; o[3] = mn; o[4] = mx; }
     }
 }
@@ -1116,6 +1145,12 @@ bool pfb_mid_supported(int M, int T) {
 }
 
 int pfb_mid_launch(int M, int T, const PfbMidCall &c, hipStream_t st, long long *grid_out) {
+    // every store of a hop past the end of the call -- and, in a DIAG build's ablation mode, EVERY store -- lands in the
+    // sink row at [0, M): refuse a launch whose sink is missing or shorter than a row (the two memory-access faults of
+    // round 2 came from a work-in-progress build of exactly that path)
+    if (!grid_out && (!c.sink || c.sink_elems < (size_t)M))
+        return set_err(WH_E_ARG, "pfb_mid_launch: sink row missing or shorter than M=%d", M);
+    if (!grid_out && !(c.stats_only & 1) && !c.out) return set_err(WH_E_ARG, "pfb_mid_launch: null output");
     if (T == 9) {
 #define X(M_, R_, GH_, NWF_, WPE_, PB_, PADN_, IMGX_, TREG_, LSP_, R8_) \
     if (M == M_) return mid_launch_t<MidCfg<M_, 9, R_, GH_, NWF_, WPE_, PB_, PADN_, IMGX_, TREG_, LSP_, R8_>>(c, st, grid_out);
@@ -1146,6 +1181,8 @@ bool spectrum_mid_supported(int N) {
 }
 
 int spectrum_mid_launch(int N, const SpectrumMidCall &c, hipStream_t st) {
+    if (!c.sink || c.sink_elems < (size_t)N || !c.out)
+        return set_err(WH_E_ARG, "spectrum_mid_launch: null output, or sink row missing / shorter than N=%d", N);
 #define X(N_, R_, GH_, NWF_, WPE_, PB_, PADN_, IMGX_, TREG_, LSP_, R8_) \
     if (N == N_) return spectrum_launch_t<MidCfg<N_, 1, R_, GH_, NWF_, WPE_, PB_, PADN_, IMGX_, TREG_, LSP_, R8_>>(c, st);
     WH_SPEC_CONFIGS(X)

@@ -181,7 +181,7 @@ extern "C" int wh_spectrum_run(wh_spectrum *s, const float *d_iq, size_t n_frame
     if (s->shaped && s->path != 1) {
         SpectrumMidCall c;
         c.x = reinterpret_cast<const float2 *>(d_iq); c.frame_stride = frame_stride; c.n_frames = (long long)n_frames;
-        c.out = d_power_db; c.sink = s->d_sink; c.window = s->d_window; c.tw = s->d_tw; c.cu_count = s->cu_count;
+        c.out = d_power_db; c.sink = s->d_sink; c.sink_elems = (size_t)s->N; c.window = s->d_window; c.tw = s->d_tw; c.cu_count = s->cu_count;
         return spectrum_mid_launch(s->N, c, as_stream(stream));
     }
     hipLaunchKernelGGL(spectrum_kernel, dim3((unsigned)n_frames), dim3(256), s->smem, as_stream(stream),

@@ -85,8 +85,12 @@ class AsyncStatsReducer:
             _lib.check(_lib.lib.wh_stats_merge(o.data_ptr(), o.shape[0], o.shape[1], res.data_ptr(), _lib.stream_ptr(torch)),
                        "wh_stats_merge")
             return res
-        return torch.cat([out[:, :, 0:3].sum(0), out[:, :, 3].min(0).values[:, None],
-                          out[:, :, 4].max(0).values[:, None]], dim=1)
+        # same convention as the kernel: a rank whose count is 0 contributes no min / max; nothing anywhere: +inf / -inf
+        has = out[:, :, 2] > 0
+        inf = torch.tensor(float("inf"), dtype=out.dtype, device=out.device)
+        mn = torch.where(has, out[:, :, 3], inf).min(0).values
+        mx = torch.where(has, out[:, :, 4], -inf).max(0).values
+        return torch.cat([out[:, :, 0:3].sum(0), mn[:, None], mx[:, None]], dim=1)
 
 
 def gather_measurements(meas, group=None):
