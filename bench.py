@@ -415,7 +415,7 @@ def secondary_c4fm(torch, steps: int = 2):
     import numpy as np
     import wavehip
     from oracle.c4fm_c import C4FMDemodulatorRef
-    from test_gpu_fullsize import config4_streams
+    from signals import config4_streams
 
     fs, C, call, secs = 48000, 64, 4800, 10
     n = fs * secs
@@ -449,7 +449,39 @@ def secondary_c4fm(torch, steps: int = 2):
         gd = np.concatenate(got[c])
         mism += int(gd.size != rd.size) + int(np.count_nonzero(gd[:rd.size] != rd[:gd.size]))
     sym_s = C * n / (fs / 4800) / el
-    return {"workload": "64 independent P25 C4FM streams @48 kHz (seeds 1000+k, offsets U(-400,400) Hz, 20 dB), 10 s, 100 ms calls (configs[3])",
+    # the same streams at the control-channel monitor's call size: 72 000 samples = 1.5 s per demodulate()
+    # (trunking/system.py:1548-1549 -> control_channel.py:230-231), 6 calls; dibits of 4 channels against the C oracle
+    big, nb = 72000, 6 * 72000
+    bank.reserve(big)
+    got_b = [[] for _ in range(C)]
+
+    def run_big(collect):
+        bank.reset()
+        for s in range(0, nb, big):
+            d, sf, cnt = bank.demodulate_device(xs[:, s:s + big])
+            if collect:
+                dc, cc = d.cpu().numpy(), cnt.cpu().numpy()
+                for c in range(C):
+                    got_b[c].append(dc[c, :cc[c]].copy())
+
+    run_big(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run_big(False)
+    torch.cuda.synchronize()
+    el_b = (time.perf_counter() - t0) / steps
+    mism_b = 0
+    for c in (0, 21, 42, 63):
+        ref = C4FMDemodulatorRef(sample_rate=fs, atan_mode=1)
+        rd = np.concatenate([ref.demodulate(host[c, s:s + big])[0] for s in range(0, nb, big)])
+        gd = np.concatenate(got_b[c])
+        mism_b += int(gd.size != rd.size) + int(np.count_nonzero(gd[:rd.size] != rd[:gd.size]))
+    production = {"call_samples": big, "calls": nb // big, "seconds_of_signal": nb / fs, "seconds_per_block": round(el_b, 4),
+                  "x_realtime_per_channel": round(nb / fs / el_b, 1), "channels_checked": 4,
+                  "dibit_mismatches_vs_c_oracle": mism_b}
+    return {"production_call_size": production,
+            "workload": "64 independent P25 C4FM streams @48 kHz (seeds 1000+k, offsets U(-400,400) Hz, 20 dB), 10 s, 100 ms calls (configs[3])",
             "symbols_per_s": round(sym_s, 0), "samples_msps_x_channels": round(C * n / el / 1e6, 2),
             "x_realtime_per_channel": round(secs / el, 1), "seconds_per_10s_block": round(el, 4),
             "channels_checked": C, "dibit_mismatches_vs_c_oracle": mism,
@@ -527,7 +559,7 @@ def main() -> None:
     stats2 = [torch.zeros((M, 5), dtype=torch.float64, device="cuda") for _ in range(2)]
     scan = min(1024, hops)
     ch.profile(True)
-    reducer = AsyncStatsReducer() if (world > 1 and not rehearsal) else None
+    reducer = AsyncStatsReducer() if world > 1 else None      # (rehearsal: the same reducer, staged through the host for gloo)
     it = [0]
 
     def step():
@@ -600,7 +632,7 @@ def main() -> None:
                                    f"2^{args.log2n} samples per step per GPU, one stream per GPU "
                                    "(BASELINE.json configs[2] / configs[4])",
                        "samples_per_step_per_gpu": n, "hops_per_step": hops, "channels": M,
-                       "scan_window_hops": scan, "collective": (f"{dist.get_backend()} all_gather(stats 40 KB/GPU), " + ("async, 1 per step" if reducer is not None else "synchronous all-reduces (rehearsal)")) if world > 1 else "none",
+                       "scan_window_hops": scan, "collective": (f"{dist.get_backend()} all_gather(stats 40 KB/GPU), " + ("async, 1 per step" + (" (gloo rehearsal: staged through the host)" if rehearsal else ""))) if world > 1 else "none",
                        "scanner_reduce_ms": None if reduce_ms is None else round(reduce_ms, 4)},
             "input_msps": round(world * n * args.steps / elapsed / 1e6, 1),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -187,6 +187,16 @@ def p25_head_stream_iq(fs: int = 48000, seed: int = 1500, reps: int = 3, snr_db:
     return iq, tx
 
 
+def config4_streams(C: int = 64, fs: int = 48000, n: int = 480000):
+    """C independent C4FM streams (seeds 1000+k, frequency offsets U(-400, 400) Hz, SNR 20 dB)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    offs = np.random.default_rng(4).uniform(-400.0, 400.0, size=C)
+    with ThreadPoolExecutor(8) as ex:
+        rows = list(ex.map(lambda k: c4fm_iq(n, fs, 1000 + k, snr_db=20.0, freq_offset_hz=float(offs[k]))[0], range(C)))
+    return np.stack(rows), offs
+
+
 # --------------------------------------------------------------------------
 # P25 Phase-2 style pi/4-DQPSK transmitter (for the CQPSK demodulator rows)
 # --------------------------------------------------------------------------

@@ -119,16 +119,6 @@ def test_config2_nbfm_10s_int16_bank():
         assert abs(float(m[199, k, 0]) - met["rssi_db"]) <= 2e-4
 
 
-def config4_streams(C: int = 64, fs: int = 48000, n: int = 480000):
-    """C independent C4FM streams (seeds 1000+k, frequency offsets U(-400, 400) Hz, SNR 20 dB)."""
-    from concurrent.futures import ThreadPoolExecutor
-
-    offs = np.random.default_rng(4).uniform(-400.0, 400.0, size=C)
-    with ThreadPoolExecutor(8) as ex:
-        rows = list(ex.map(lambda k: S.c4fm_iq(n, fs, 1000 + k, snr_db=20.0, freq_offset_hz=float(offs[k]))[0], range(C)))
-    return np.stack(rows), offs
-
-
 def test_config4_c4fm_64ch_10s_bit_exact():
     """BASELINE configs[3] as SURVEY 8(d) specifies it: 64 INDEPENDENT P25 C4FM streams at 48 kHz (seeds 1000+k, offsets
     U(-400, 400) Hz, SNR 20 dB), 10 s each, fed in 100 ms calls -- dibits AND soft symbols of ALL 64 channels
@@ -139,7 +129,7 @@ def test_config4_c4fm_64ch_10s_bit_exact():
     from oracle.c4fm_c import C4FMDemodulatorRef
 
     fs, C, call, n = 48000, 64, 4800, 480000
-    host, _ = config4_streams(C, fs, n)
+    host, _ = S.config4_streams(C, fs, n)
     xs = torch.from_numpy(host).cuda()
     bank = wavehip.C4FMBank(C, fs, max_samples_per_call=call)
     got_d = [[] for _ in range(C)]

@@ -40,6 +40,7 @@ class AsyncStatsReducer:
         self._send = [None, None]   # ping-pong copies of the submitted block (the collective reads them asynchronously)
         self._recv = [None, None]
         self._k = 0
+        self._dev = None
         self.submitted = 0
 
     def submit(self, stats):
@@ -50,10 +51,13 @@ class AsyncStatsReducer:
         world = dist.get_world_size(self.group)
         k = self._k
         self._k ^= 1
-        if self._send[k] is None or self._send[k].shape != stats.shape or self._send[k].device != stats.device:
-            self._send[k] = torch.empty_like(stats, memory_format=torch.contiguous_format)
-            self._recv[k] = torch.empty((world * stats.shape[0],) + tuple(stats.shape[1:]), dtype=stats.dtype,
-                                        device=stats.device)
+        # gloo (the one-GPU rehearsal and the CPU tests) gathers host tensors only: device statistics are staged through
+        # the host there and come back to the device in wait(), so that the merge kernel runs as it does over RCCL
+        self._dev = stats.device
+        cdev = torch.device("cpu") if (stats.is_cuda and dist.get_backend(self.group) == "gloo") else stats.device
+        if self._send[k] is None or self._send[k].shape != stats.shape or self._send[k].device != cdev:
+            self._send[k] = torch.empty(stats.shape, dtype=stats.dtype, device=cdev)
+            self._recv[k] = torch.empty((world * stats.shape[0],) + tuple(stats.shape[1:]), dtype=stats.dtype, device=cdev)
         self._send[k].copy_(stats)
         work = dist.all_gather_into_tensor(self._recv[k], self._send[k], group=self.group, async_op=True)
         self._pending = (work, self._recv[k].view((world,) + tuple(stats.shape)))
@@ -69,6 +73,8 @@ class AsyncStatsReducer:
         work, out = self._pending
         self._pending = None
         work.wait()
+        if out.device != self._dev:
+            out = out.to(self._dev)
         return self.merge_gathered(out) if merge else out
 
     @staticmethod
