@@ -177,6 +177,8 @@ struct FmArgs {
     const float *nco_c; // [K] f32(-2 pi off/fs); 0 => no mix
     const double *taps; // [ntaps]
     int fmt, N, K, n_out, ntaps, down, d0, TO, R;   // R: output tiles per workgroup (fused kernel)
+    const float2 *tphase;   // fir_phase: float2 [21][32] = the tap pairs (trev[q down + 2 rp], trev[.. + 1]) by block and phase pair
+    int fir_phase;      // fused kernel: != 0 -> the decimating FIR runs in its polyphase register form (fm_fir_phases), TO = 128
     float scale;        // fs / (2 pi 75000)
     int demod;          // 0 FM discriminator, 1 AM envelope, 2 SSB product detector, 3/4/5 SAM dsb/usb/lsb
     double bfo_c;       // 2 pi bfo_hz (SSB), sample_rate in fs_d
@@ -225,10 +227,18 @@ __device__ __forceinline__ fm_v2f fast_atan2f_x2(fm_v2f y, fm_v2f x) {
 // int16 input come in with one 8-byte load, and the NCO / mix / discriminator / atan2 arithmetic of the pair goes out as
 // packed instructions.  Per sample the operations are those of the one-sample form (same results for a sample whichever
 // slot computes it): 87 -> about 65 issue slots per sample and channel.
+// Power sums (rms_normalize needs sum v^2 of the whole row, the metrics sum |base|^2): float32 PER PASS AND LANE -- a
+// lane meets at most ~30 samples in a pass -- folded into the float64 run sums once per pass.  A pass's step grid is
+// anchored at the pass's first window index, and which pass computes a sample does not depend on how the row is cut
+// into runs (see the ownership rule in the kernel), so the sums stay independent of the batch size bit for bit.
+// BASE: sum |x|^2 of the RAW samples -- |x e^(j theta)| = |x|, the reference's rssi_db is the power of the mixed but
+// unfiltered chunk (capture.py:330-334), i.e. the same number for every channel of a capture up to the rounding of
+// |e^(j theta)| (1e-7) -- so only channel 0's workgroups take it and the finalize kernel shares it.
 template <bool CHECK, int FMT, bool MIX>
 __device__ __forceinline__ void fm_phase1(const FmArgs &a, float *fm_s, int i_lo, int i_hi, int n_lo, int N, float c,
                                           size_t in_base, int own_lo, int own_hi, int lane, int wave,
-                                          double &p_base, double &p_fm) {
+                                          double &p_base, double &p_fm, const bool base) {
+    float sb_a = 0.f, sb_b = 0.f, sf_a = 0.f, sf_b = 0.f;   // the pass's float32 sums: a-slots and b-slots apart
     // interior passes (no bounds checks) load one step ahead: the pair of the NEXT step is in flight while this one is
     // mixed and discriminated (the last step re-reads its own pair)
     typedef typename std::conditional<FMT == 1, short4, float4>::type raw_t;   // two IQ pairs, 4-byte aligned
@@ -256,6 +266,8 @@ __device__ __forceinline__ void fm_phase1(const FmArgs &a, float *fm_s, int i_lo
             if (va) { const float2 v = load_iq(a.in, FMT, in_base + na); bx.x = v.x; by.x = v.y; }
             if (vb) { const float2 v = load_iq(a.in, FMT, in_base + nb); bx.y = v.x; by.y = v.y; }
         }
+        fm_v2f pw = {0.f, 0.f};
+        if (base) pw = __builtin_elementwise_fma(bx, bx, by * by);   // raw power (uniform branch: channel 0 only)
         if (MIX) {   // mix_fast on the pair
             const fm_v2f C_HI = {0.15915494f, 0.15915494f}, C_LO = {6.4206382e-09f, 6.4206382e-09f};
             const fm_v2f ph = fm_v2f{c, c} * fm_v2f{(float)na, (float)nb};
@@ -279,28 +291,86 @@ __device__ __forceinline__ void fm_phase1(const FmArgs &a, float *fm_s, int i_lo
             if (!(va && na >= 1)) v.x = 0.f;
             if (!(vb && nb >= 1)) v.y = 0.f;
         }
-        const fm_v2f pw = __builtin_elementwise_fma(bx, bx, by * by);
         if (lane > 0 && ia < i_hi) {
             fm_s[ia] = v.x;
             if (!CHECK || (va && na >= own_lo && na < own_hi)) {
-                // float64 running sums: the result must not depend on how a row is cut into runs (batch size)
-                p_base += (double)pw.x;
-                p_fm += (double)(v.x * v.x);
+                sb_a += pw.x;
+                sf_a = fmaf(v.x, v.x, sf_a);
             }
         }
         if (ib < i_hi) {
             fm_s[ib] = v.y;
             if (!CHECK || (vb && nb >= own_lo && nb < own_hi)) {
-                p_base += (double)pw.y;
-                p_fm += (double)(v.y * v.y);
+                sb_b += pw.y;
+                sf_b = fmaf(v.y, v.y, sf_b);
             }
         }
     }
+    p_base += (double)(sb_a + sb_b);
+    p_fm += (double)(sf_a + sf_b);
+}
+
+// ---- phase 2 in polyphase register form ---------------------------------------------------------------------------
+// y[o] = sum_i w[o D + i] trev[i] (D = down) read the window from LDS once per MAC pair and tap pair: 5 bytes per MAC,
+// 77 GB of LDS reads per 32 x 200 x 120 000 launch = 1.1 ms at the chip's 69 TB/s of LDS bandwidth -- the launch was
+// bound by that, not by its arithmetic (cutting 16 % of the VALU work of phase 1 did not move it).  Here the sum is
+// split by tap PHASE: i = q D + 2 rp + c (q < 21 blocks, rp < D / 2 phase pairs, c < 2), lane (e, rp) of a wave owns
+// phase pair rp for the outputs o = o0 + 2 j + e of the wave's quarter of the tile, keeps its 21 tap pairs in registers
+// for the whole kernel and the 21 window pairs w[(o + q) D + 2 rp .. + 1] in a register ring that advances by two
+// blocks per output: 2 eight-byte LDS reads per 21 packed FMAs (0.7 B per MAC incl. the ring fill).  The 25 phase
+// sums of an output are added across the half-wave by five DPP adds (row_shr 1 / 2 / 4 / 8, row_bcast 15), in a fixed
+// order, float32 (the 42-term lane sums too; error against scipy's float64 ~3e-7 of the output scale, as before).
+constexpr int FIR_Q = 21;          // resample_poly designs 20 max(up, down) + 1 taps: 21 blocks of `down` for up == 1
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    // v[lane] + v[source lane of the DPP pattern] (0 where the pattern has no source / the row is masked)
+    const int sh = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true);
+    return v + __int_as_float(sh);
+}
+
+template <int NS>
+__device__ __forceinline__ void fm_fir_phases(const float *fm_s, const fm_v2f (&T)[FIR_Q], int D, int PP, int lane, int wave,
+                                              int mcnt, float *out) {
+    const int e = lane >> 5, rp = lane & 31;
+    const int rpc = rp < PP ? rp : PP - 1;               // idle lanes (zero taps) read valid words
+    const int o0 = wave * 2 * NS + e;
+    const float *wb = fm_s + o0 * D + 2 * rpc;
+    fm_v2f x[FIR_Q];
+#pragma unroll
+    for (int q = 0; q < FIR_Q; ++q) x[q] = *reinterpret_cast<const fm_v2f *>(wb + q * D);
+    float outv = 0.f;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        fm_v2f a0 = {0.f, 0.f}, a1 = a0, a2 = a0;
+#pragma unroll
+        for (int q = 0; q < FIR_Q; q += 3) {
+            a0 = __builtin_elementwise_fma(x[(q + 2 * j) % FIR_Q], T[q], a0);
+            a1 = __builtin_elementwise_fma(x[(q + 1 + 2 * j) % FIR_Q], T[q + 1], a1);
+            a2 = __builtin_elementwise_fma(x[(q + 2 + 2 * j) % FIR_Q], T[q + 2], a2);
+        }
+        if (j + 1 < NS) {   // blocks o + 21, o + 22 replace blocks o, o + 1
+            x[(2 * j) % FIR_Q] = *reinterpret_cast<const fm_v2f *>(wb + (2 * j + FIR_Q) * D);
+            x[(2 * j + 1) % FIR_Q] = *reinterpret_cast<const fm_v2f *>(wb + (2 * j + FIR_Q + 1) * D);
+        }
+        const fm_v2f a = (a0 + a1) + a2;
+        float sum = a.x + a.y;
+        sum = dpp_add<0x111, 0xf>(sum);      // row_shr:1
+        sum = dpp_add<0x112, 0xf>(sum);      // row_shr:2
+        sum = dpp_add<0x114, 0xf>(sum);      // row_shr:4
+        sum = dpp_add<0x118, 0xf>(sum);      // row_shr:8  -> lane 15 of every row: the row's total
+        sum = dpp_add<0x142, 0xa>(sum);      // row_bcast:15 into rows 1 and 3 -> lanes 31 / 63: the half-waves' totals
+        const float y_even = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sum), 31));
+        const float y_odd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sum), 63));
+        outv = lane == j ? y_even : (lane == 32 + j ? y_odd : outv);   // lane (e, j) keeps the output of step j
+    }
+    const int o = wave * 2 * NS + 2 * rp + e;            // lane (e, l) holds the output of step l
+    if (rp < NS && o < mcnt) out[o] = outv;
 }
 
 // ROWS: the unfused chains' decimating FIR (the window is copied from a.rows_src instead of computed by phase 1)
 template <bool ROWS>
-__global__ __launch_bounds__(256) void fmbank_fused_kernel(FmArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) void fmbank_fused_kernel(FmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float *taps_s = reinterpret_cast<float *>(smem_raw);                       // taps rounded to float32, reversed
     float *fm_s = reinterpret_cast<float *>(smem_raw + (size_t)((a.ntaps + 1) & ~1) * sizeof(float));
@@ -316,14 +386,34 @@ __global__ __launch_bounds__(256) void fmbank_fused_kernel(FmArgs a) {
     const int W = a.ntaps + (a.TO - 1) * a.down;     // window length
     const int adv = a.TO * a.down;                   // window advance per tile
     const int keep = W - adv;                        // samples carried over (may be <= 0: then nothing is reused)
-    const int own_lo = t_lo * adv;
-    const int own_hi = t_hi >= n_tiles ? N : t_hi * adv;   // exclusive
+    // Which run sums a sample: the one whose tile computes it in its STANDARD pass.  Tile T > 0 of a run adds the window
+    // indices [keep, W) = samples [T adv + dlt, (T + 1) adv + dlt), dlt = d0 + 1 - down; the first tile of a run has to
+    // produce the whole window, but its part [0, keep) belongs to earlier tiles -- so it is made by a pass of its own
+    // that sums nothing, and every sample is summed by the same pass with the same step grid wherever the row is cut.
+    const int dlt = keep > 0 ? a.d0 + 1 - a.down : 0;
+    const bool split_first = keep > 0 && dlt >= 0 && dlt <= keep;
+    const int own_lo = t_lo == 0 ? 0 : (split_first ? t_lo * adv + dlt : t_lo * adv);
+    const int own_hi = t_hi >= n_tiles ? N : (split_first ? t_hi * adv + dlt : t_hi * adv);   // exclusive
 
     // taps reversed (trev[i] = h[ntaps-1-i]) so that y[o] = sum_i fm_s[o*down + i] * trev[i] walks both arrays
     // upwards; one zero pad makes the count even for the paired reads
     const int ntp = (a.ntaps + 1) & ~1;
-    for (int j = tid; j < ntp; j += 256) taps_s[j] = j < a.ntaps ? (float)a.taps[a.ntaps - 1 - j] : 0.0f;
-    if (tid == 0) fm_s[W] = 0.0f;   // partner of the zero tap pad
+    const bool phases = a.fir_phase != 0;
+    fm_v2f Tq[FIR_Q];                // polyphase form: the lane's 21 tap pairs (phase pair rp = lane & 31), kept for the run
+    if (phases) {
+        fm_s = reinterpret_cast<float *>(smem_raw);       // no tap table in LDS
+#pragma unroll
+        for (int q = 0; q < FIR_Q; ++q) {
+            const float2 t = a.tphase[q * 32 + (lane & 31)];
+            Tq[q] = fm_v2f{t.x, t.y};
+        }
+        if (tid < 64) fm_s[W + tid] = 0.0f;   // the last block of the last output reaches 49 words past the window (zero taps)
+    } else {
+#pragma unroll
+        for (int q = 0; q < FIR_Q; ++q) Tq[q] = fm_v2f{0.f, 0.f};
+        for (int j = tid; j < ntp; j += 256) taps_s[j] = j < a.ntaps ? (float)a.taps[a.ntaps - 1 - j] : 0.0f;
+        if (tid == 0) fm_s[W] = 0.0f;   // partner of the zero tap pad
+    }
 
     const float c = a.nco_c[k];
     const bool do_mix = c != 0.0f;
@@ -336,10 +426,30 @@ __global__ __launch_bounds__(256) void fmbank_fused_kernel(FmArgs a) {
         if (mcnt > a.TO) mcnt = a.TO;
         const int n_lo = m0 * a.down + a.d0 - (a.ntaps - 1);   // chunk index of window slot 0
         // phase 1: the whole window for the first tile of the run, the new part afterwards
-        const int i_lo = (tile == t_lo || keep <= 0) ? 0 : keep;
-        // interior: every sample this pass touches (incl. the idle lanes of its last 127-sample step) exists and is owned
-        const bool interior = n_lo + i_lo >= (own_lo > 1 ? own_lo : 1) + 1 && n_lo + W <= own_hi && n_lo + W + 128 <= N;
-#define WH_P1(CHK, F, M) fm_phase1<CHK, F, M>(a, fm_s, i_lo, W, n_lo, N, c, in_base, own_lo, own_hi, lane, wave, p_base, p_fm)
+        const bool head = !ROWS && split_first && tile == t_lo && tile > 0;   // first tile of a later run: [0, keep) first
+        const int i_lo = ((tile == t_lo && !head) || keep <= 0) ? 0 : keep;
+        // interior: every sample this pass touches (incl. lane 0's predecessor sample and the idle lanes of its last
+        // 127-sample step) exists, every sample it stores is owned and has a predecessor
+        const bool interior = n_lo + i_lo >= (own_lo > 1 ? own_lo : 1) && n_lo + W <= own_hi && n_lo + W + 128 <= N;
+        const bool base = k == 0;
+#define WH_P1X(CHK, F, M, LO, HI, OL, OH, PB, PF) \
+    fm_phase1<CHK, F, M>(a, fm_s, LO, HI, n_lo, N, c, in_base, OL, OH, lane, wave, PB, PF, base)
+#define WH_P1(CHK, F, M) WH_P1X(CHK, F, M, i_lo, W, own_lo, own_hi, p_base, p_fm)
+        if (head) {
+            // the carried part of the window, owned by earlier runs: computed, not summed (empty ownership range; its sums
+            // go to scratch variables)
+            double nb_ = 0.0, nf_ = 0.0;
+            const bool in_a = n_lo >= 1 && n_lo + keep + 128 <= N;
+#define WH_P1A(CHK, F, M) WH_P1X(CHK, F, M, 0, keep, 0, 0, nb_, nf_)
+            if (in_a) {
+                if (a.fmt == 1) { if (do_mix) WH_P1A(false, 1, true); else WH_P1A(false, 1, false); }
+                else            { if (do_mix) WH_P1A(false, 0, true); else WH_P1A(false, 0, false); }
+            } else {
+                if (a.fmt == 1) { if (do_mix) WH_P1A(true, 1, true); else WH_P1A(true, 1, false); }
+                else            { if (do_mix) WH_P1A(true, 0, true); else WH_P1A(true, 0, false); }
+            }
+#undef WH_P1A
+        }
         if (ROWS) {
             // unfused chains (IIR stages, AGC, AM / SSB fronts): the rows are in memory already; this kernel is their
             // decimating FIR (the generic one-wave-per-output resampler took 13 of 18 ms for 32 default-config NBFM
@@ -357,10 +467,14 @@ __global__ __launch_bounds__(256) void fmbank_fused_kernel(FmArgs a) {
             else            { if (do_mix) WH_P1(true, 0, true); else WH_P1(true, 0, false); }
         }
 #undef WH_P1
+#undef WH_P1X
         __syncthreads();  // window (and, first time, taps) visible
 
         // phase 2: y[m0+o] = sum_i fm_s[o*down + i] * trev[i].
-        if (a.TO > 96 && a.TO <= 128 && (a.TO & 3) == 0 && (a.down & 1) == 0) {
+        if (phases) {
+            fm_fir_phases<16>(fm_s, Tq, a.down, a.down >> 1, lane, wave, mcnt,
+                              a.audio + ((size_t)chunk * a.K + k) * a.n_out + m0);
+        } else if (a.TO > 96 && a.TO <= 128 && (a.TO & 3) == 0 && (a.down & 1) == 0) {
             // 8 lanes share 4 outputs: each lane takes a contiguous 1/8 of the (paired) taps for all 4, so a tap pair
             // is read once per 8 MACs; packed FMAs; float32 partial sums over 32 pairs, added in float64 (error ~3e-7
             // of the output scale; scipy accumulates in float64).
@@ -458,7 +572,7 @@ __global__ __launch_bounds__(256) void fmbank_fused_kernel(FmArgs a) {
     __syncthreads();
     if (tid == 0) {
         double *acc = a.acc + ((size_t)chunk * a.K + k) * 2;
-        atomicAdd(acc, red[0] + red[1] + red[2] + red[3]);
+        if (k == 0) atomicAdd(acc, red[0] + red[1] + red[2] + red[3]);   // shared by the chunk's channels (finalize)
         atomicAdd(acc + 1, red[4] + red[5] + red[6] + red[7]);
     }
 }
@@ -485,7 +599,7 @@ __global__ __launch_bounds__(256) void chan_front_kernel(FmArgs a) {
         // [b_lo, b_hi)
         double pb = 0.0, pf = 0.0;
         const bool interior = b_lo >= 2 && b_hi + 128 <= N;
-#define WH_F1(CHK, F, M) fm_phase1<CHK, F, M>(a, fm, b_lo, b_hi, 0, N, c, in_base, b_lo, b_hi, lane, wave, pb, pf)
+#define WH_F1(CHK, F, M) fm_phase1<CHK, F, M>(a, fm, b_lo, b_hi, 0, N, c, in_base, b_lo, b_hi, lane, wave, pb, pf, true)
         if (interior) {
             if (a.fmt == 1) { if (do_mix) WH_F1(false, 1, true); else WH_F1(false, 1, false); }
             else            { if (do_mix) WH_F1(false, 0, true); else WH_F1(false, 0, false); }
@@ -1280,14 +1394,18 @@ __global__ __launch_bounds__(64 * ROWS_MAXW) void chan_rows_scan_kernel(float *r
 // [rows][n_out] -- what the caller sends on needs no second pass and only that buffer has to cross PCIe.
 __global__ __launch_bounds__(256) void fmbank_finalize_kernel(float *audio, const double *acc, float *metrics,
                                                               int N, int n_fm, int n_out, int post,
-                                                              const float *squelch_db, int K, int wire, void *wire_out) {
+                                                              const float *squelch_db, int K, int wire, void *wire_out,
+                                                              int shared_base) {
     const size_t row = blockIdx.x;
+    // shared_base: sum |base|^2 sits in channel 0's slot of the chunk (fused FM kernel: the power of the mixed chunk is the
+    // power of the raw chunk, the same for every channel)
+    const double base_pw = acc[(shared_base ? row - row % K : row) * 2];
     float *au = audio + row * n_out;
     // squelch (capture.py:2918-2921): rssi below the channel's threshold -> zeros (metrics keep the unsquelched power)
     bool squelched = false;
     if (squelch_db) {
         const float sq = squelch_db[row % K];
-        const float rssi = (float)(10.0 * log10(acc[row * 2] / (double)N + 1e-10));
+        const float rssi = (float)(10.0 * log10(base_pw / (double)N + 1e-10));
         squelched = sq == sq && rssi < sq;   // NaN = no squelch configured
     }
     short *w16 = wire == 1 ? reinterpret_cast<short *>(wire_out) + row * n_out : nullptr;
@@ -1332,7 +1450,7 @@ __global__ __launch_bounds__(256) void fmbank_finalize_kernel(float *audio, cons
         mx = fmaxf(fmaxf(rm[0], rm[1]), fmaxf(rm[2], rm[3]));
         bad = rb[0] | rb[1] | rb[2] | rb[3];
         float *m = metrics + row * 4;
-        m[0] = (float)(10.0 * log10(ac[0] / (double)N + 1e-10));
+        m[0] = (float)(10.0 * log10(base_pw / (double)N + 1e-10));
         m[1] = (float)(10.0 * log10((double)(p / (float)n_out) + 1e-10));
         m[2] = mx;
         m[3] = bad ? 0.f : 1.f;
@@ -1663,6 +1781,8 @@ struct wh_chanbank {
     size_t cap_chunks = 0;
     bool fused = false;
     bool rows_fir = false;   // unfused chain whose resampler is the fused kernel's decimating FIR
+    int fir_phase = 0;       // the FIR's polyphase register form (see fm_fir_phases)
+    float2 *d_tphase = nullptr;
     int TO = 128;
     size_t smem = 0;
     int post = 0;
@@ -1846,11 +1966,31 @@ extern "C" int wh_chanbank_create(wh_chanbank **out, const wh_chanbank_cfg *c) {
             while (to > 100 && bytes(to) > 32000) to -= 4;
             if (bytes(to) <= 32000) TO = to;
         }
+        // polyphase register form of the FIR (fm_fir_phases): 21 tap blocks of `down`, 17..32 phase pairs, tiles of 128
+        // outputs, no tap table in LDS (29.7 KB at 1001 taps / 50:1: five workgroups per CU)
+        b->fir_phase = 0;
+        if ((c->down & 1) == 0 && c->down >= 34 && c->down <= 64 && c->ntaps <= FIR_Q * c->down &&
+            c->ntaps + 127 * c->down + 64 <= FM_MAX_SPAN) {
+            b->fir_phase = 1;
+            TO = 128;
+            // tap pairs by block q and phase pair rp: (trev[q down + 2 rp], trev[q down + 2 rp + 1]), trev[i] = h[ntaps - 1 - i]
+            // rounded to float32; zero beyond the filter and for the idle lanes rp >= down / 2
+            std::vector<float2> tp((size_t)FIR_Q * 32, make_float2(0.f, 0.f));
+            for (int q = 0; q < FIR_Q; ++q)
+                for (int rp = 0; rp < c->down / 2; ++rp) {
+                    const int i = q * c->down + 2 * rp;
+                    tp[(size_t)q * 32 + rp] = make_float2(i < c->ntaps ? (float)c->h_taps[c->ntaps - 1 - i] : 0.f,
+                                                          i + 1 < c->ntaps ? (float)c->h_taps[c->ntaps - 2 - i] : 0.f);
+                }
+            WH_HIP(hipMalloc(&b->d_tphase, tp.size() * sizeof(float2)));
+            WH_HIP(hipMemcpy(b->d_tphase, tp.data(), tp.size() * sizeof(float2), hipMemcpyHostToDevice));
+        }
         if (c->ntaps + (TO - 1) * c->down <= FM_MAX_SPAN) {
             b->fused = plain_fm;
             b->rows_fir = !plain_fm;
             b->TO = TO;
-            b->smem = (size_t)((c->ntaps + 1) & ~1) * sizeof(float) + (size_t)(c->ntaps + 1 + (TO - 1) * c->down) * sizeof(float);
+            b->smem = b->fir_phase ? (size_t)(c->ntaps + (TO - 1) * c->down + 64) * sizeof(float)
+                                   : (size_t)((c->ntaps + 1) & ~1) * sizeof(float) + (size_t)(c->ntaps + 1 + (TO - 1) * c->down) * sizeof(float);
             WH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fmbank_fused_kernel<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->smem));
             WH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fmbank_fused_kernel<true>),
@@ -1864,6 +2004,7 @@ extern "C" int wh_chanbank_create(wh_chanbank **out, const wh_chanbank_cfg *c) {
 extern "C" void wh_chanbank_destroy(wh_chanbank *b) {
     if (!b) return;
     (void)hipFree(b->d_nco);
+    (void)hipFree(b->d_tphase);
     (void)hipFree(b->d_squelch);
     (void)hipFree(b->d_pow);
     (void)hipFree(b->d_G);
@@ -1946,6 +2087,8 @@ extern "C" int wh_chanbank_run_wire(wh_chanbank *b, const void *d_in, size_t n_c
     a.down = c.down;
     a.d0 = c.d0;
     a.TO = b->TO;
+    a.fir_phase = b->fir_phase;
+    a.tphase = b->d_tphase;
     a.R = 1;
     a.scale = (float)((double)c.sample_rate / (2.0 * M_PI * 75000.0));
     a.demod = c.demod;
@@ -2080,7 +2223,7 @@ extern "C" int wh_chanbank_run_wire(wh_chanbank *b, const void *d_in, size_t n_c
     }
     hipLaunchKernelGGL(fmbank_finalize_kernel, dim3((unsigned)rows), dim3(256), 0, st, d_audio, b->d_acc, d_metrics,
                        c.chunk_len, b->nr ? b->nr_len : c.chunk_len, c.n_out, b->post, b->d_squelch, c.n_channels, wire_format,
-                       d_wire);
+                       d_wire, b->fused ? 1 : 0);
     WH_LAUNCH_CHECK();
     return WH_OK;
 }
@@ -2107,7 +2250,7 @@ extern "C" int wh_channel_signal_metrics(const void *d_in, int input_format, siz
     WH_HIP(hipMemsetAsync(d_acc, 0, (size_t)K * 2 * sizeof(double), st));
     FmArgs a;
     a.in = d_in; a.audio = nullptr; a.acc = d_acc; a.fm_out = d_rows; a.rows_src = nullptr; a.skip_fm_sum = 0; a.nco_c = d_nco; a.taps = nullptr;
-    a.fmt = input_format; a.N = (int)n; a.K = K; a.n_out = 0; a.ntaps = 0; a.down = 1; a.d0 = 0; a.TO = 1; a.R = 1;
+    a.fmt = input_format; a.N = (int)n; a.K = K; a.n_out = 0; a.ntaps = 0; a.down = 1; a.d0 = 0; a.TO = 1; a.R = 1; a.fir_phase = 0; a.tphase = nullptr;
     a.scale = 0.f; a.demod = 1; a.bfo_c = 0.0; a.fs_d = (double)sample_rate; a.pll_alpha = a.pll_beta = 0.0;
     const int per_block = 4 * 63 * 16;
     hipLaunchKernelGGL(chan_front_kernel, dim3((unsigned)((n + per_block - 1) / per_block), K, 1), dim3(256), 0, st, a);
