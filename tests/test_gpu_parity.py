@@ -1107,7 +1107,7 @@ def test_a7_pfb_prefetch_forms_agree(wh):
     assert all(torch.equal(ref, o) for v in outs for o in outs[v])
 
 
-@pytest.mark.parametrize("M", [320, 1024, 256, 96, 2048, 640])
+@pytest.mark.parametrize("M", [320, 1024, -1024, 256, 96, 2048, 640])
 def test_a13_statistics_only_filterbank(wh, M):
     """wh_pfb_run_stats: the filterbank in statistics-only mode (last pass reduces |y|^2 in registers, no channel outputs
     written) == wh_pfb_channel_stats over the full output of the same input: {sum, sum of squares, count, min, max} per
@@ -1117,13 +1117,16 @@ def test_a13_statistics_only_filterbank(wh, M):
     count without a shaped kernel is refused."""
     import torch
 
+    # M = 1024 has two statistics-only kernels: the tuned 1024-channel kernel's own form (the default) and the shaped
+    # kernel's (M = -1024 here); each is compared with the full output of ITS kernel family -- the two factor their FFTs
+    # differently, and float32 rounding differences of y become 1e-7 relative differences of |y|^2
+    path = "shaped" if M != 1024 else "auto"
+    M = abs(M)
     fs, bw = M * 25_000, 25_000
     g = torch.Generator(device="cuda").manual_seed(60 + M)
     n1, n2 = M // 2 * 700 + 33, M // 2 * 5 + 7
     x = torch.view_as_complex(torch.randn(n1 + n2, 2, device="cuda", generator=g).mul_(0.5))
-    # (M = 1024: the full output of the SAME kernel family -- the tuned 1024-channel kernel factors its FFT differently, and
-    # float32 rounding differences of y become 1e-7 relative differences of |y|^2)
-    full, st = wh.PolyphaseChannelizer(fs, bw).tune(path="shaped"), wh.PolyphaseChannelizer(fs, bw)
+    full, st = wh.PolyphaseChannelizer(fs, bw).tune(path=path), wh.PolyphaseChannelizer(fs, bw).tune(path=path)
     assert full.channel_count == M
     ref = None
     got = None
@@ -1138,7 +1141,7 @@ def test_a13_statistics_only_filterbank(wh, M):
     record_margin(err, tol=2e-6)
     assert err <= 2e-6, err
     i16 = torch.from_numpy(S.pack_iq16_np(x[:n1].cpu().numpy())).cuda()
-    a, b = wh.PolyphaseChannelizer(fs, bw).tune(path="shaped"), wh.PolyphaseChannelizer(fs, bw)
+    a, b = wh.PolyphaseChannelizer(fs, bw).tune(path=path), wh.PolyphaseChannelizer(fs, bw).tune(path=path)
     r16 = a.channel_stats_device(a.process_device(i16)).cpu().numpy()
     s16 = b.process_stats_device(i16).cpu().numpy()
     assert np.array_equal(r16[:, 2:], s16[:, 2:]) and np.max(np.abs(r16[:, :2] - s16[:, :2]) / r16[:, :2]) <= 2e-6

@@ -20,9 +20,13 @@ struct Args {
     int rotate;           // 1: workgroup w starts its walk at group (w * 7) % groups_per_run
     int xcd;              // 1: run = (b % 8) * runs_per_xcd + b / 8
     int wide;             // 1: a wave's store instruction covers 1 KiB contiguous
+    int halo;             // 1: every group also re-reads the 9 half-blocks before it (what a workgroup without a carried
+                          //    register window would do: those are L2 hits when neighbouring groups run on the same XCD)
 };
 
 __global__ __launch_bounds__(256) void walk_kernel(Args a) {
+    extern __shared__ float occ_lds[];      // dynamic LDS only limits the resident workgroups per CU
+    if (a.hops < 0) occ_lds[threadIdx.x] = 0.f;
     const long long runs = (a.hops + a.R - 1) / a.R;
     long long run = blockIdx.x;
     if (a.xcd) {
@@ -41,6 +45,16 @@ __global__ __launch_bounds__(256) void walk_kernel(Args a) {
             const long long hh = h + j < a.hops ? h + j : a.hops - 1;
             pre[2 * j] = a.in[hh * 512 + t];
             pre[2 * j + 1] = a.in[hh * 512 + 256 + t];
+        }
+        if (a.halo) {
+            float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int j = 1; j <= 9; ++j) {
+                const long long hh = h - j >= 0 ? h - j : 0;
+                const float2 u = a.in[hh * 512 + t], v = a.in[hh * 512 + 256 + t];
+                acc.x += u.x + v.x; acc.y += u.y + v.y;
+            }
+            pre[0].x += acc.x; pre[0].y += acc.y;
         }
     };
     load_group(g0);
@@ -75,25 +89,28 @@ int main(int argc, char **argv) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    const int Rs[] = {64, 128, 256, 252, 244, 200, 136, 120, 512, 500};
-    for (int wide = 0; wide < 2; ++wide)
+    const int Rs[] = {4, 16, 64, 256};
+    for (int wide = 0; wide < 1; ++wide)
         for (int xcd = 0; xcd < 2; ++xcd)
-            for (int rot = 0; rot < 2; ++rot)
+            for (int occ = 1; occ <= 8; occ *= 2)
                 for (int R : Rs) {
-                    Args a{in, out, hops, R, rot, xcd, wide};
+                    const int rot = 0, halo = 0;
+                    const size_t lds = occ == 8 ? 0 : (size_t)(160 * 1024 / occ) - 1024;
+                    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(walk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+                    Args a{in, out, hops, R, rot, xcd, wide, halo};
                     const long long runs = (hops + R - 1) / R;
                     const unsigned grid = (unsigned)(((runs + 7) / 8) * 8);
                     float best = 1e9f;
                     for (int rep = 0; rep < 6; ++rep) {
                         CK(hipEventRecord(e0));
-                        hipLaunchKernelGGL(walk_kernel, dim3(grid), dim3(256), 0, 0, a);
+                        hipLaunchKernelGGL(walk_kernel, dim3(grid), dim3(256), lds, 0, a);
                         CK(hipEventRecord(e1));
                         CK(hipEventSynchronize(e1));
                         float ms;
                         CK(hipEventElapsedTime(&ms, e0, e1));
                         if (rep > 0 && ms < best) best = ms;
                     }
-                    printf("wide=%d xcd=%d rot=%d R=%4d  %.4f ms  %.2f TB/s\n", wide, xcd, rot, R, best,
+                    printf("xcd=%d WGs/CU=%d R=%4d  %.4f ms  %.2f TB/s\n", xcd, occ, R, best,
                            24.0 * (double)n / best * 1e-9);
                     fflush(stdout);
                 }

@@ -63,6 +63,7 @@ struct PfbFastArgs {
     int groups_per_wg;
     int n_wg;
     long long max_block;    // last half-block (512 samples) fully inside the input: prefetches past it are clamped
+    double *stats_ws;       // STATS: one row [4][1024] float64 per workgroup (sum p, sum p^2, min, max)
 #ifdef WH_DIAG
     int ablate;             // diagnostics build only (WH_PFB_ABLATE): 1 = suppress stores
 #endif
@@ -73,7 +74,10 @@ struct PfbFastArgs {
 // reported in issue order (tools/ubench/vmcnt_order.hip), so vmcnt(8) -- the eight output stores issued after the
 // prefetch -- retires the prefetch and leaves the stores in flight.  With ordinary loads hipcc's wait for the
 // prefetched registers is vmcnt(0): every group drained its predecessor's stores before its arm MAC could finish.
-template <int FMT, bool GLDS = false>
+// STATS: statistics-only mode (A13, the scanner's pass): stage 3 turns its 16 outputs per lane into float32 powers, the four
+// hops of a group meet in LDS (each wave's finished image is free by then) and thread t folds them into the accumulators
+// of its four channels t + 256 q; nothing is stored but one [4][1024] row per workgroup at the end.
+template <int FMT, bool GLDS = false, bool STATS = false>
 __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
     constexpr int PRE_BYTES = GLDS ? GH * FHOP * (FMT == 1 ? 4 : 8) : 0;   // GH half-blocks of samples
     // the DMA target is double-buffered: the copy for group g+2 is issued by whichever wave finishes group g+1's arm MAC
@@ -97,7 +101,13 @@ __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
     long long g0 = (long long)run * a.groups_per_wg;
     long long g1 = g0 + a.groups_per_wg;
     if (g1 > a.n_groups) g1 = a.n_groups;
-    if (g0 >= g1) return;
+    if (g0 >= g1) {
+        if (STATS) {   // (never the case with the launcher's grid; an empty row all the same)
+            double *row = a.stats_ws + (size_t)blockIdx.x * 4 * FM;
+            for (int c = threadIdx.x; c < FM; c += 256) { row[c] = 0.0; row[FM + c] = 0.0; row[2 * FM + c] = INFINITY; row[3 * FM + c] = 0.0; }
+        }
+        return;
+    }
 
     // taps: arms[k][j] for k = t, t+256, t+512, t+768, kept as 18 register PAIRS (tap e = q * 9 + j is half e & 1 of pair
     // e / 2): the arm MAC below is packed -- (re, im) * tap as one v_pk_fma_f32 with the tap broadcast from its half of the
@@ -118,6 +128,11 @@ __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
     tw256[t] = a.tw1024[(4 * (t & 15) * (t >> 4)) & 1023];
     __syncthreads();
 
+    StAcc sacc[STATS ? 4 : 1];
+    if (STATS) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) stacc_init(sacc[q]);
+    }
     long long h = a.first_hop + g0 * GH;  // first hop of this run
     // windows: wA[i] = x[(h-8+i)*512 + t], wB[i] = x[(h-8+i)*512 + t + 256], i = 0..8 carried,
     // i = 9..12 filled per group
@@ -263,7 +278,12 @@ __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
                 v[14] = make_float2(r7.x, r7.y);  v[15] = make_float2(r7.z, r7.w);
             }
             fft16(v);
-            {
+            if (STATS) {
+                // lane l holds X[l + 64 j] of hop h + wave: their powers go to the wave's own (finished) image, [channel]
+                float *pwv = reinterpret_cast<float *>(L);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) pwv[lane + 64 * j] = stat_power(v[j].x, v[j].y);
+            } else {
                 // 16-byte stores (+2.3 % over 8-byte ones): lanes 2m / 2m+1 swap half of their outputs so that
                 // the even lane owns (X[2m + 64 j], X[2m+1 + 64 j]) for j < 8 and the odd lane the pair for j >= 8
                 const bool even = (lane & 1) == 0;
@@ -283,6 +303,18 @@ __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
                 }
             }
         }
+        if (STATS) {
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int w = 0; w < GH; ++w)      // the group's hops in order
+                    stacc_add(sacc[q], reinterpret_cast<const float *>(lds + w * LDS_HOP)[t + 256 * q]);
+            if (((g - g0 + 1) & 3) == 0) {        // open float32 blocks are folded after 16 hops
+#pragma unroll
+                for (int q = 0; q < 4; ++q) stacc_fold(sacc[q]);
+            }
+        }
         if (GLDS) {
             // the prefetch is older than this group's 8 stores: retire it, keep them in flight.  vmcnt counts loads,
             // stores and LDS-DMA together, in issue order (MI355X_MICROARCH.md, "s_waitcnt vmcnt(N) waits until all
@@ -291,7 +323,8 @@ __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
             if (a.ablate) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else
 #endif
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if (STATS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no stores behind the prefetch in this mode
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         }
         __syncthreads();
         if (GLDS && g + 1 < g1) {
@@ -308,6 +341,18 @@ __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
                     wB[9 + i] = p32[i * FHOP + t + 256];
                 }
             }
+        }
+    }
+    if (STATS) {
+        double *row = a.stats_ws + (size_t)blockIdx.x * 4 * FM;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            stacc_fold(sacc[q]);
+            const int c = t + 256 * q;
+            row[c] = sacc[q].s;
+            row[FM + c] = sacc[q].s2;
+            row[2 * FM + c] = (double)sacc[q].mn;
+            row[3 * FM + c] = (double)sacc[q].mx;
         }
     }
 }
@@ -329,6 +374,7 @@ struct PfbGenArgs {
     long long n_hops;
     long long hop0b;     // first hop of range B (blocks [n_hops, n_hops + n_hops_b)); lets the head
     long long n_hops_b;  // (carried history) and the ragged tail of the fast path share one launch
+    long long row_b;     // output row of range B's first hop (statistics-only mode: a compact scratch block); -1 = its hop index
 };
 
 __device__ __forceinline__ float2 gen_block(const PfbGenArgs &a, long long g, int k) {
@@ -354,7 +400,8 @@ __global__ __launch_bounds__(256) void pfb_generic_kernel(PfbGenArgs a) {
         sm[k] = make_float2(re, im);
     }
     __syncthreads();
-    float2 *o = a.out + (size_t)h * M;
+    const bool in_b = (long long)blockIdx.x >= a.n_hops;
+    float2 *o = a.out + (size_t)((in_b && a.row_b >= 0) ? a.row_b + (h - a.hop0b) : h) * M;
     if (a.n_radix > 0) {
         // Stockham autosort, mixed radix (DIF), ping-pong between sm[0:M) and sm[M:2M): a pass of radix r with
         // sub-length n and stride s (n*s = M), m = n/r: for p < m, q < s
@@ -832,6 +879,7 @@ struct wh_pfb {
     int cur = 0;
     double *d_part = nullptr;   // stats partials
     float2 *d_sink = nullptr;   // [M] write-only scratch row of the shaped kernels
+    float2 *d_edge = nullptr;   // M = 1024 statistics-only mode: outputs of the <= 8 head and <= 3 tail hops [11][1024]
     double *d_stats_ws = nullptr;   // statistics-only mode: one [4][M] row per workgroup of the launch
     size_t stats_ws_rows = 0;
     int cu_count = 256;
@@ -884,6 +932,7 @@ extern "C" int wh_pfb_create(wh_pfb **out, int M, int T, const double *h_arms) {
     WH_HIP(hipMalloc(&p->d_hist[1], (size_t)M * T * sizeof(float2)));
     WH_HIP(hipMalloc(&p->d_part, (size_t)64 * M * 4 * sizeof(double)));
     WH_HIP(hipMalloc(&p->d_sink, (size_t)M * sizeof(float2)));
+    if (M == FM && T == FT) WH_HIP(hipMalloc(&p->d_edge, (size_t)11 * FM * sizeof(float2)));
     WH_HIP(hipMemcpy(p->d_arms, arms.data(), arms.size() * sizeof(float), hipMemcpyHostToDevice));
     WH_HIP(hipMemcpy(p->d_tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice));
     WH_HIP(hipMemset(p->d_hist[0], 0, (size_t)M * T * sizeof(float2)));
@@ -900,6 +949,7 @@ extern "C" void wh_pfb_destroy(wh_pfb *p) {
     (void)hipFree(p->d_hist[1]);
     (void)hipFree(p->d_part);
     (void)hipFree(p->d_sink);
+    (void)hipFree(p->d_edge);
     (void)hipFree(p->d_stats_ws);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
@@ -957,7 +1007,7 @@ extern "C" size_t wh_pfb_hops(const wh_pfb *p, size_t n) {
 }
 
 static int launch_generic(wh_pfb *p, const void *d_iq, int fmt, float *d_out, long long hop0, long long n_hops,
-                          hipStream_t st, long long hop0b = 0, long long n_hops_b = 0) {
+                          hipStream_t st, long long hop0b = 0, long long n_hops_b = 0, long long row_b = -1) {
     if (n_hops_b < 0) n_hops_b = 0;
     if (n_hops <= 0 && n_hops_b <= 0) return WH_OK;
     if (n_hops < 0) n_hops = 0;
@@ -970,7 +1020,7 @@ static int launch_generic(wh_pfb *p, const void *d_iq, int fmt, float *d_out, lo
     a.tw = p->d_tw;
     a.M = p->M; a.T = p->T; a.log2M = p->log2M;
     a.hop0 = hop0; a.n_hops = n_hops;
-    a.hop0b = hop0b; a.n_hops_b = n_hops_b;
+    a.hop0b = hop0b; a.n_hops_b = n_hops_b; a.row_b = row_b;
     // factor M into radices 4, 2, 3, 5 (mixed-radix Stockham); anything else falls back to the direct DFT
     a.n_radix = 0;
     {
@@ -1264,6 +1314,60 @@ extern "C" int wh_pfb_run_stats(wh_pfb *p, const void *d_iq, int input_format, s
     const long long H = (long long)wh_pfb_hops(p, n);
     if (H == 0) return WH_OK;
     if (!d_iq || !d_stats) return set_err(WH_E_ARG, "wh_pfb_run_stats: null buffer");
+    if (p->M == FM && p->T == FT && p->path != 3 && p->d_edge) {
+        // 1024 channels: the tuned kernel in its statistics-only form (radix-16 stages; 1.13 ms without its stores against
+        // the shaped kernel's 1.36 at 2 workgroups per CU), head / tail hops through the per-hop kernel into a scratch block
+        int rc;
+        const long long n_groups = H > 8 ? (H - 8) / GH : 0;
+        const long long head = H < 8 ? H : 8;
+        const long long tail0 = 8 + n_groups * GH, tailn = H > 8 ? H - tail0 : 0;
+        int acc = accumulate;
+        if (n_groups > 0) {
+            PfbFastArgs a;
+            a.x = d_iq; a.out = nullptr; a.arms = p->d_arms; a.tw1024 = p->d_tw;
+            a.first_hop = 8; a.n_groups = n_groups;
+            int gpw = 64;
+            long long nwg = (n_groups + gpw - 1) / gpw;
+            while (gpw > 2 && nwg < (long long)p->cu_count * 8) { gpw >>= 1; nwg = (n_groups + gpw - 1) / gpw; }
+            if (p->gpw_override > 0) { gpw = p->gpw_override; nwg = (n_groups + gpw - 1) / gpw; }
+            a.groups_per_wg = gpw; a.n_wg = (int)nwg;
+            a.max_block = (long long)(n / (size_t)FHOP) - 1;
+#ifdef WH_DIAG
+            a.ablate = 0;
+#endif
+            if ((size_t)nwg > p->stats_ws_rows) {   // rows of [4][M]: grow (synchronises; a steady call size never does)
+                WH_HIP(hipStreamSynchronize(st));
+                (void)hipFree(p->d_stats_ws);
+                p->d_stats_ws = nullptr;
+                p->stats_ws_rows = 0;
+                WH_HIP(hipMalloc(&p->d_stats_ws, (size_t)nwg * 4 * p->M * sizeof(double)));
+                p->stats_ws_rows = (size_t)nwg;
+            }
+            a.stats_ws = p->d_stats_ws;
+            if (p->prof) WH_HIP(hipEventRecord(p->ev0, st));
+            if (input_format == 1) hipLaunchKernelGGL((pfb1024_kernel<1, true, true>), dim3((unsigned)nwg), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((pfb1024_kernel<0, false, true>), dim3((unsigned)nwg), dim3(256), 0, st, a);
+            WH_LAUNCH_CHECK();
+            if (p->prof) {
+                WH_HIP(hipEventRecord(p->ev1, st));
+                p->ev_valid = true;
+            }
+            if ((rc = pfb_stats_rows_reduce(p->d_stats_ws, (int)nwg, -1, p->M, (double)(n_groups * GH), d_stats, acc, st)) != WH_OK)
+                return rc;
+            acc = 1;
+        }
+        if ((rc = launch_generic(p, d_iq, input_format, reinterpret_cast<float *>(p->d_edge), 0, head, st, tail0, tailn, head)) != WH_OK)
+            return rc;
+        if ((rc = wh_pfb_channel_stats(p, reinterpret_cast<const float *>(p->d_edge), (size_t)(head + tailn), d_stats, acc, stream)) != WH_OK)
+            return rc;
+        int nxt = p->cur ^ 1;
+        int tot = p->M * p->T;
+        hipLaunchKernelGGL(pfb_hist_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, d_iq, input_format, p->d_hist[p->cur],
+                           p->d_hist[nxt], p->M, p->T, H);
+        WH_LAUNCH_CHECK();
+        p->cur = nxt;
+        return WH_OK;
+    }
     PfbMidCall c;
     c.x = d_iq; c.fmt = input_format; c.n = n;
     c.hist = p->d_hist[p->cur]; c.new_hist = p->d_hist[p->cur ^ 1];

@@ -25,6 +25,36 @@ struct PfbMidCall {
     int stats_accumulate;    // merge into stats_out instead of overwriting
 };
 
+// ---- the activity statistic of a channel (A13; the repo's own definition, consumed by the scanner / classifier as dB
+// levels): p = float32(float32(re^2) + float32(im^2)) of every output; {sum p, sum p^2} are taken in float32 over short
+// blocks of hops (at most 16 of a lane's consecutive visits) and the block sums added in float64; min / max are exact
+// float32.  Every producer (the statistics-only kernels and wh_pfb_channel_stats over a stored output) computes the
+// same p bit for bit, so count, min and max agree exactly; the sums agree to the float32 block rounding (<= 2e-6
+// relative, typically 2e-7): the grouping into blocks is the kernel's business and not part of the definition.
+// (Round 2 took p, p^2 and the four reductions in float64: 16 issue slots per output against ~5 here.)
+struct StAcc {
+    double s, s2;          // float64 sums of the folded blocks
+    float fs, fs2, mn, mx; // open block (float32), exact extremes
+};
+__device__ __forceinline__ void stacc_init(StAcc &a) { a.s = 0.0; a.s2 = 0.0; a.fs = 0.f; a.fs2 = 0.f; a.mn = INFINITY; a.mx = 0.f; }
+__device__ __forceinline__ void stacc_fold(StAcc &a) {
+    a.s += (double)a.fs; a.s2 += (double)a.fs2;
+    a.fs = 0.f; a.fs2 = 0.f;
+}
+__device__ __forceinline__ float stat_power(float re, float im) {
+    return __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));   // no contraction into an FMA: every producer gets the same bits
+}
+__device__ __forceinline__ void stacc_add(StAcc &a, float pw) {
+    a.fs = __fadd_rn(a.fs, pw);
+    a.fs2 = fmaf(pw, pw, a.fs2);
+    a.mn = fminf(a.mn, pw);
+    a.mx = fmaxf(a.mx, pw);
+}
+// workgroup rows [rows][4][M] = {sum p, sum p^2, min, max} (float64) -> d_stats [M][5] = {sum p, sum p^2, hops, min, max};
+// row `skip` (or -1) holds nothing
+int pfb_stats_rows_reduce(const double *ws, int rows, int skip, int M, double hops, double *stats, int accumulate,
+                          hipStream_t st);
+
 // true when a compiled instance exists for (M, T)
 bool pfb_mid_supported(int M, int T);
 // one launch: head hops (carried history), the runs, and the history update.  Returns a WH_* status.  With grid_out

@@ -462,34 +462,6 @@ __device__ __forceinline__ void mid_last_units(const v2f *img, v2f *out, v2f *si
     }
 }
 
-// Activity statistic of a channel (A13; the repo's own definition, consumed by the scanner / classifier as dB levels):
-// p = float32(float32(re^2) + float32(im^2)) of every output; {sum p, sum p^2} are taken in float32 over short blocks of
-// hops (at most 16 of a lane's consecutive visits) and the block sums added in float64; min / max are exact float32.
-// Both producers (this kernel and wh_pfb_channel_stats over a stored output) compute the same p bit for bit, so count,
-// min and max agree exactly; the sums agree to the float32 block rounding (<= 2e-6 relative, typically 2e-7): the
-// grouping into blocks is the kernel's business and not part of the definition.  (Round 2 took p, p^2 and the four
-// reductions in float64: 16 issue slots per output against ~5 here, which made the statistics-only pass -- no stores
-// at all -- slower than the pass that writes 4.3 GB.)
-struct StAcc {
-    double s, s2;          // float64 sums of the folded blocks
-    float fs, fs2, mn, mx; // open block (float32), exact extremes
-};
-__device__ __forceinline__ void stacc_init(StAcc &a) { a.s = 0.0; a.s2 = 0.0; a.fs = 0.f; a.fs2 = 0.f; a.mn = INFINITY; a.mx = 0.f; }
-__device__ __forceinline__ void stacc_fold(StAcc &a) {
-    a.s += (double)a.fs; a.s2 += (double)a.fs2;
-    a.fs = 0.f; a.fs2 = 0.f;
-}
-__device__ __forceinline__ float stat_power(v2f y) {
-    const v2f sq = y * y;                  // one packed multiply: (re^2, im^2), each rounded
-    return __fadd_rn(sq.x, sq.y);          // no contraction into an FMA: the stored-output kernel must get the same bits
-}
-__device__ __forceinline__ void stacc_add(StAcc &a, float pw) {
-    a.fs = __fadd_rn(a.fs, pw);
-    a.fs2 = fmaf(pw, pw, a.fs2);
-    a.mn = fminf(a.mn, pw);
-    a.mx = fmaxf(a.mx, pw);
-}
-
 // last pass in statistics-only mode: same butterflies, outputs reduced into the lane's accumulators instead of stored.
 // Units chunk-major: ui = c S_NHG + hg.
 template <class C>
@@ -512,7 +484,7 @@ __device__ __forceinline__ void mid_last_stats(const v2f *img, int lane, int wav
         bfly(v);
         if (hop < limit) {
 #pragma unroll
-            for (int k = 0; k < r; ++k) stacc_add(acc[ci * r + k], stat_power(v[k]));
+            for (int k = 0; k < r; ++k) stacc_add(acc[ci * r + k], stat_power(v[k].x, v[k].y));
         }
     }
 }
@@ -1188,6 +1160,14 @@ int spectrum_mid_launch(int N, const SpectrumMidCall &c, hipStream_t st) {
     WH_SPEC_CONFIGS(X)
 #undef X
     return set_err(WH_E_ARG, "spectrum_mid_launch: no instance for N=%d", N);
+}
+
+int pfb_stats_rows_reduce(const double *ws, int rows, int skip, int M, double hops, double *stats, int accumulate,
+                          hipStream_t st) {
+    hipLaunchKernelGGL(mid_stats_reduce_kernel, dim3((M + 63) / 64), dim3(64, 16), 0, st, ws, rows, skip, M, hops, stats,
+                       accumulate);
+    WH_LAUNCH_CHECK();
+    return WH_OK;
 }
 
 const char *pfb_mid_kernel_name() { return "pfb_mid_kernel"; }

@@ -120,6 +120,35 @@ class PolyphaseChannelizer:
             _lib.check(_lib.lib.wh_pfb_tune(self._h, self.TUNE_KEYS[k], int(v)), "wh_pfb_tune")
         return self
 
+    def plan(self, samples, out=None, candidates=None, rounds: int = 4) -> int:
+        """Measure-and-pick planning for calls of this size, on THIS device (the FFTW-planner idea): how many hops a
+        workgroup walks decides how the launch's read and write streams meet the HBM channels, and the best length
+        differs between otherwise identical MI355X boxes by more than any kernel change of rounds 2-3 moved the time
+        (tools/ubench/stream_shapes.hip: the same no-arithmetic walk moves 4.9-6.3 TB/s depending on run length, mapping
+        and resident workgroups; tools/pfb_gpw_sweep.py: one box is fastest at 32 hops, the next at 256).  Every
+        candidate is timed on the caller's buffers by HIP events in interleaved rounds; the fastest median is set with
+        tune(hops_per_run=...) and returned (0 = the built-in choice).  Outputs and carried history are unaffected (every
+        run length gives the same bits); the history is restored afterwards."""
+        import statistics
+
+        M1024 = self.channel_count == 1024 and self.taps_per_channel == 9
+        if candidates is None:      # 1024 channels: groups of 4 hops per workgroup; shaped kernels: hops per run
+            candidates = (0, 8, 10, 12, 24, 32, 64) if M1024 else (0, 16, 32, 64, 128)
+        hist = self.arm_history
+        times: dict[int, list[float]] = {c: [] for c in candidates}
+        self.profile(True)
+        for r in range(rounds + 1):
+            for c in candidates:
+                self.tune(hops_per_run=c)
+                out = self.process_device(samples, out)
+                if r:                                     # the first round warms every variant up
+                    times[c].append(self.last_kernel_ms())
+        best = min(candidates, key=lambda c: statistics.median(times[c]))
+        self.tune(hops_per_run=best)
+        self.arm_history = hist
+        self.planned = {"hops_per_run_setting": best, "median_ms": {int(c): round(statistics.median(t), 4) for c, t in times.items()}}
+        return best
+
     def profile(self, enable: bool = True) -> None:
         _lib.check(_lib.lib.wh_pfb_profile(self._h, 1 if enable else 0), "wh_pfb_profile")
 
