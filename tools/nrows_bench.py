@@ -2,7 +2,7 @@
 """Throughput of the smaller rows (N2 soft sync / BCH, LSM and Phase-2 CQPSK banks) on synthetic input.  Diagnostics."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "wavecap-sdr_amd"), os.path.join(ROOT, "tests")]
+sys.path[:0] = [ROOT, os.environ.get("WAVEHIP_PKG_DIR", os.path.join(ROOT, "wavecap-sdr_amd")), os.path.join(ROOT, "tests")]
 import numpy as np, torch
 import signals as S, wavehip
 

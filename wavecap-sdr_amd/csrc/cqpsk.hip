@@ -45,6 +45,8 @@ struct CqArgs {
     double sps, c_kp, c_ki, c_maxf, t_kp, t_ki, t_maxdev;
     uint8_t *dibits;
     double2 *symbols;          // optional [C][cap]
+    double2 *symws;            // [C][symcap]: the symbols when the caller wants none (the decode kernel reads them)
+    size_t symcap;
     size_t cap;
     int *counts;
 };
@@ -77,10 +79,12 @@ __global__ __launch_bounds__(256) void k_cq_rrc(CqArgs a) {
 }
 
 __device__ __forceinline__ double interp1(double v0, double v1, double v2, double v3, double mu) {
+    // (x / 2.0 written as x * 0.5: the same double bit for bit -- halving is exact -- without the IEEE division sequence;
+    // four of them per call made a symbol cost ~1 600 cycles)
     double c0 = v1;
-    double c1 = DD(DS(v2, v0), 2.0);
-    double c2 = DS(DA(DS(v0, DD(DM(5.0, v1), 2.0)), DM(2.0, v2)), DD(v3, 2.0));
-    double c3 = DA(DD(DS(v3, v0), 2.0), DD(DM(3.0, DS(v1, v2)), 2.0));
+    double c1 = DM(DS(v2, v0), 0.5);
+    double c2 = DS(DA(DS(v0, DM(DM(5.0, v1), 0.5)), DM(2.0, v2)), DM(v3, 0.5));
+    double c3 = DA(DM(DS(v3, v0), 0.5), DM(DM(3.0, DS(v1, v2)), 0.5));
     return DA(c0, DM(mu, DA(c1, DM(mu, DA(c2, DM(mu, c3))))));
 }
 
@@ -144,58 +148,130 @@ __device__ __forceinline__ double cq_atan2(double y, double x) {
     return copysign(a, y);
 }
 
-// ONE WAVE PER CHANNEL, every lane running the same scalar loop (uniform control flow: the symbol branch costs a wave only
-// when ITS channel has a symbol; with one lane per channel every wave paid for it on every sample).  The loop is a
-// dependent float64 chain (Costas phase -> sincos -> rotate -> atan2 -> error -> phase), so a channel's time is latency
-// bound and channels scale across the 1024 SIMDs, not across lanes.  Input: the wave loads 64 samples at a time with one
-// coalesced 1 KiB read and hands them out by readlane.
-__global__ __launch_bounds__(64) void k_cq_seq(CqArgs a) {
-    const int c = blockIdx.x, lane = threadIdx.x;
+// ONE WAVE PER CHANNEL.  The Costas loop feeds back every sample, but only through a PHASE: the sample is rotated by
+// exp(-j phi_n) and the detector takes the angle of the result, which is arg(x_n) - phi_n (mod 2 pi) -- so the feedback
+// path itself is the short recurrence
+//     d = theta_n - phi;  e = d - rint(d / q) q;  f = clamp(f + ki e);  phi = wrap(phi + kp e + f)        (q = pi / 4)
+// with theta_n = arg(x_n) known in advance, and the two transcendental evaluations per sample (sincos of phi for the
+// rotation, atan2 for the angle) leave the sequential path (round 2 walked ~120 dependent float64 instructions per sample,
+// 22 ms per 64 channels x 1 s).  Per block of 64 samples: lane l computes theta_l (one atan2 per lane, parallel), the wave
+// runs the recurrence over the block as uniform scalar code and hands phi_n to lane n, the lanes rotate their samples
+// (sincos in parallel, the same products as before), then the timing loop (Mueller-Muller, one decision per symbol) walks
+// the rotated samples.  Against the reference's complex128 arithmetic the detector angle differs by the rounding of
+// theta - phi instead of that of the rotated product (both ~2e-16; the loop is contractive): symbols agree to ~1e-13,
+// dibits exactly (tests: 1e-9 / equal).
+struct CqCostas {
+    double phase, freq;
+};
+
+// the recurrence over the m samples of a block: theta (lane-resident) in, phi_n (the phase sample n is rotated by: the
+// loop's phase BEFORE its update) out in lane n
+__device__ __forceinline__ double cq_costas_block(CqCostas &c, double theta, int m, int lane, double kp, double ki, double maxf) {
+    const double q = PI_D / 4, inv_q = 1.0 / (PI_D / 4);
+    double myphi = 0.0;
+    for (int j = 0; j < m; ++j) {
+        const double th = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(theta), j),
+                                           __builtin_amdgcn_readlane(__double2loint(theta), j));
+        myphi = lane == j ? c.phase : myphi;
+        const double d = DS(th, c.phase);
+        const double err = DS(d, DM(rint(DM(d, inv_q)), q));
+        c.freq = fmin(fmax(DA(c.freq, DM(ki, err)), -maxf), maxf);
+        double ph = DA(c.phase, DA(DM(kp, err), c.freq));
+        // the reference's `while phase > pi: phase -= 2 pi` loops as selects: |phase| <= pi before the step and the step is
+        // at most max_freq + kp pi / 8 < 2 pi, so each loop runs at most once (no branch on a vector compare per sample)
+        ph = ph > PI_D ? DS(ph, 2 * PI_D) : ph;
+        ph = ph < -PI_D ? DA(ph, 2 * PI_D) : ph;
+        c.phase = ph;
+    }
+    return myphi;
+}
+
+// Two waves per channel, a pipeline over blocks of 64 samples: wave 0 runs the carrier loop of block i (angles, the phase
+// recurrence, the rotation) and leaves the rotated samples in LDS, wave 1 runs the timing loop over block i - 1; one
+// workgroup barrier per block.  (One wave doing both took 4.1 + 6.5 ms per 64 channels x 1 s; the timing loop is the
+// longer stage.)
+__global__ __launch_bounds__(128) void k_cq_seq(CqArgs a) {
+    __shared__ double2 rot[2][64];
+    const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     CqState *const sp = a.st + c;
     // (field by field: a whole-struct copy of the state, with its buf[4] array, lands in scratch)
-    struct { double c_phase, c_freq, t_phase, t_integ, prev_phase; double2 prev_sym, prev_dec; } s;
-    s.c_phase = sp->c_phase; s.c_freq = sp->c_freq; s.t_phase = sp->t_phase; s.t_integ = sp->t_integ;
-    s.prev_phase = sp->prev_phase; s.prev_sym = sp->prev_sym; s.prev_dec = sp->prev_dec;
+    struct { double t_phase, t_integ; double2 prev_sym, prev_dec; } s;
+    CqCostas cl{sp->c_phase, sp->c_freq};
+    s.t_phase = sp->t_phase; s.t_integ = sp->t_integ;
+    s.prev_sym = sp->prev_sym; s.prev_dec = sp->prev_dec;
     const double2 sb0 = sp->buf[0], sb1 = sp->buf[1], sb2 = sp->buf[2], sb3 = sp->buf[3];
     const double2 *full = a.full + (size_t)c * (a.n_max + a.L - 1);
-    uint8_t *dib = a.dibits + (size_t)c * a.cap;
-    double2 *sym = a.symbols ? a.symbols + (size_t)c * a.cap : nullptr;
-    const double q = PI_D / 4, inv_q = 1.0 / (PI_D / 4);
+    double2 *sym = a.symbols ? a.symbols + (size_t)c * a.cap : a.symws + (size_t)c * a.symcap;
     const double inv_sps = 1.0 / a.sps;
     const double R2 = 0.70710678118654746;   // 1 / 1.4142135623730951 as the reference computes it (kr / inv)
-    // the 4-entry circular buffer lives in registers, rotated so that b3 is the newest (no dynamic indexing: scratch)
+    // the 4-entry circular buffer of the timing loop, oldest first
     const int bi = sp->buf_idx & 3;
-    double2 b0 = bi == 0 ? sb1 : bi == 1 ? sb2 : bi == 2 ? sb3 : sb0;
-    double2 b1 = bi == 0 ? sb2 : bi == 1 ? sb3 : bi == 2 ? sb0 : sb1;
-    double2 b2 = bi == 0 ? sb3 : bi == 1 ? sb0 : bi == 2 ? sb1 : sb2;
-    double2 b3 = bi == 0 ? sb0 : bi == 1 ? sb1 : bi == 2 ? sb2 : sb3;
+    const double2 h0 = bi == 0 ? sb1 : bi == 1 ? sb2 : bi == 2 ? sb3 : sb0;
+    const double2 h1 = bi == 0 ? sb2 : bi == 1 ? sb3 : bi == 2 ? sb0 : sb1;
+    const double2 h2 = bi == 0 ? sb3 : bi == 1 ? sb0 : bi == 2 ? sb1 : sb2;
+    const double2 h3 = bi == 0 ? sb0 : bi == 1 ? sb1 : bi == 2 ? sb2 : sb3;
+    // rotated samples (wave 1): lane l of (crl, cil) holds sample l of the block at hand, lane 63 - i of (pcr, pci) the
+    // sample i before it (so the four samples a symbol interpolates are always one readlane away)
+    double pcr = lane == 60 ? h0.x : lane == 61 ? h1.x : lane == 62 ? h2.x : lane == 63 ? h3.x : 0.0;
+    double pci = lane == 60 ? h0.y : lane == 61 ? h1.y : lane == 62 ? h2.y : lane == 63 ? h3.y : 0.0;
+#define CQ_RL(v, i) __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), (i)), __builtin_amdgcn_readlane(__double2loint(v), (i)))
     int count = 0;
-    for (int t0 = 0; t0 < a.n; t0 += 64) {
-        const double2 xl = t0 + lane < a.n ? full[t0 + lane] : make_double2(0.0, 0.0);
-        const int m = a.n - t0 < 64 ? a.n - t0 : 64;
-        for (int j = 0; j < m; ++j) {
-            double2 x;
-            {
-                const int xlo = __builtin_amdgcn_readlane(__double2loint(xl.x), j), xhi = __builtin_amdgcn_readlane(__double2hiint(xl.x), j);
-                const int ylo = __builtin_amdgcn_readlane(__double2loint(xl.y), j), yhi = __builtin_amdgcn_readlane(__double2hiint(xl.y), j);
-                x = make_double2(__hiloint2double(xhi, xlo), __hiloint2double(yhi, ylo));
-            }
+    const int nb = (a.n + 63) / 64;
+    for (int blk = 0; blk <= nb; ++blk) {
+        if (wave == 0 && blk < nb) {
+            // carrier loop of block blk: angles in parallel, the recurrence in sequence, the rotation in parallel
+            const int t0 = blk * 64;
+            const double2 xl = t0 + lane < a.n ? full[t0 + lane] : make_double2(0.0, 0.0);
+            const int m = a.n - t0 < 64 ? a.n - t0 : 64;
+            const double theta = cq_atan2(xl.y, xl.x);
+            const double phi = cq_costas_block(cl, theta, m, lane, a.c_kp, a.c_ki, a.c_maxf);
             double sn, cs;
-            cq_sincos(s.c_phase, sn, cs);
-            double cr = DS(DM(x.x, cs), DM(x.y, -sn));
-            double ci = DA(DM(x.x, -sn), DM(x.y, cs));
-            double ph = cq_atan2(ci, cr);
-            double ideal = DM(rint(DM(ph, inv_q)), q);
-            // (the reference wraps err into [-pi, pi] here: |ph - nearest multiple of pi/4| <= pi/8, the wrap never acts)
-            const double err = DS(ph, ideal);
-            s.c_freq = DA(s.c_freq, DM(a.c_ki, err));
-            s.c_freq = fmin(fmax(s.c_freq, -a.c_maxf), a.c_maxf);
-            s.c_phase = DA(s.c_phase, DA(DM(a.c_kp, err), s.c_freq));
-            while (s.c_phase > PI_D) s.c_phase = DS(s.c_phase, 2 * PI_D);
-            while (s.c_phase < -PI_D) s.c_phase = DA(s.c_phase, 2 * PI_D);
-            b0 = b1; b1 = b2; b2 = b3; b3 = make_double2(cr, ci);
-            s.t_phase = DA(s.t_phase, 1.0);
-            if (s.t_phase >= a.sps) {
+            cq_sincos(phi, sn, cs);
+            rot[blk & 1][lane] = make_double2(DS(DM(xl.x, cs), DM(xl.y, -sn)),     // sample * exp(-j phi), the reference's
+                                              DA(DM(xl.x, -sn), DM(xl.y, cs)));    // products
+        }
+        if (wave == 1 && blk >= 1) {
+            const int t0 = (blk - 1) * 64;
+            const int m = a.n - t0 < 64 ? a.n - t0 : 64;
+            const double2 rv = rot[(blk - 1) & 1][lane];
+            const double crl = rv.x, cil = rv.y;
+            // timing recovery: the reference adds 1.0 to its phase per sample and fires when it reaches sps; here the wave
+            // steps from symbol to symbol -- k = ceil(sps - phase) samples ahead (checked against the sequential
+            // additions, which are kept: they round) -- instead of testing every sample
+            int j = -1;                                // last sample consumed (block relative)
+            while (true) {
+                double need = ceil(DS(a.sps, s.t_phase));
+                int k = __builtin_amdgcn_readfirstlane((int)fmin(fmax(need, 1.0), 1.0e6));
+                if (j + k > m - 1) {                   // the next symbol lies beyond this block: consume the rest
+                    for (int i = j; i < m - 1; ++i) s.t_phase = DA(s.t_phase, 1.0);
+                    break;
+                }
+                double tp = s.t_phase, tprev = tp;
+                for (int i = 0; i < k; ++i) { tprev = tp; tp = DA(tp, 1.0); }
+                if (k > 1 && tprev >= a.sps) { tp = tprev; k -= 1; }          // (rounding of the sequential sums: at most one off)
+                else if (!(tp >= a.sps)) {
+                    if (j + k + 1 > m - 1) {           // the correction step crosses the block end
+                        s.t_phase = tp;
+                        j += k;
+                        continue;
+                    }
+                    tp = DA(tp, 1.0); k += 1;
+                }
+                j += k;
+                s.t_phase = tp;
+                double2 b0, b1, b2, b3;
+                if (__builtin_expect(j >= 3, 1)) {     // all four samples in this block (all but its first symbol)
+                    b0 = make_double2(CQ_RL(crl, j - 3), CQ_RL(cil, j - 3));
+                    b1 = make_double2(CQ_RL(crl, j - 2), CQ_RL(cil, j - 2));
+                    b2 = make_double2(CQ_RL(crl, j - 1), CQ_RL(cil, j - 1));
+                    b3 = make_double2(CQ_RL(crl, j), CQ_RL(cil, j));
+                } else {
+#define CQ_FETCH(dst, r)                                                     \
+                    if ((r) >= 0) dst = make_double2(CQ_RL(crl, (r)), CQ_RL(cil, (r)));  \
+                    else dst = make_double2(CQ_RL(pcr, 64 + (r)), CQ_RL(pci, 64 + (r)));
+                    CQ_FETCH(b0, j - 3) CQ_FETCH(b1, j - 2) CQ_FETCH(b2, j - 1) CQ_FETCH(b3, j)
+#undef CQ_FETCH
+                }
                 s.t_phase = DS(s.t_phase, a.sps);
                 double mu = DM(s.t_phase, inv_sps);
                 double sr = interp1(b0.x, b1.x, b2.x, b3.x, mu);
@@ -205,11 +281,11 @@ __global__ __launch_bounds__(64) void k_cq_seq(CqArgs a) {
                 int best = 0;
                 double bd = 0.0;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const double kr = (k == 0 || k == 3) ? R2 : -R2, ki = (k < 2) ? R2 : -R2;
+                for (int kk = 0; kk < 4; ++kk) {
+                    const double kr = (kk == 0 || kk == 3) ? R2 : -R2, ki = (kk < 2) ? R2 : -R2;
                     const double dx = DS(kr, sr), dy = DS(ki, si);
                     const double d = fma(dx, dx, dy * dy);
-                    if (k == 0 || d < bd) { bd = d; best = k; }
+                    if (kk == 0 || d < bd) { bd = d; best = kk; }
                 }
                 double dr = (best == 0 || best == 3) ? R2 : -R2, di = best < 2 ? R2 : -R2;
                 double e1 = DS(DM(s.prev_dec.x, sr), DM(-s.prev_dec.y, si));
@@ -220,29 +296,61 @@ __global__ __launch_bounds__(64) void k_cq_seq(CqArgs a) {
                 s.t_phase = DA(s.t_phase, DA(DM(a.t_kp, e), s.t_integ));
                 s.prev_sym = make_double2(sr, si);
                 s.prev_dec = make_double2(dr, di);
-                double p = cq_atan2(si, sr);
-                double dp = DS(p, s.prev_phase);
-                dp = dp > PI_D ? DS(dp, 2 * PI_D) : dp;
-                dp = dp < -PI_D ? DA(dp, 2 * PI_D) : dp;
-                long long idx = (long long)rint(DM(DA(dp, PI_D), inv_q));
-                idx = ((idx % 8) + 8) % 8;
+                // (the differential decode of the symbol -- an atan2 and a rounding, no feedback -- is k_cq_decode's)
                 if ((size_t)count < a.cap) {
-                    if (lane == 0) {
-                        dib[count] = (uint8_t)(idx >> 1);
-                        if (sym) sym[count] = make_double2(sr, si);
-                    }
+                    if (lane == 0) sym[count] = make_double2(sr, si);
                     count++;
                 }
-                s.prev_phase = p;
+            }
+            // the block becomes history: lane 63 - i <- the sample i before the next block
+            {
+                const int sh = 64 - m;                 // 0 for a full block
+                const double ncr = __shfl(crl, lane - sh), nci = __shfl(cil, lane - sh);
+                const double ocr = __shfl(pcr, (lane + m) & 63), oci = __shfl(pci, (lane + m) & 63);
+                pcr = lane >= sh ? ncr : ocr;
+                pci = lane >= sh ? nci : oci;
             }
         }
+        __syncthreads();
     }
-    if (lane == 0) {
-        sp->c_phase = s.c_phase; sp->c_freq = s.c_freq; sp->t_phase = s.t_phase; sp->t_integ = s.t_integ;
-        sp->prev_phase = s.prev_phase; sp->prev_sym = s.prev_sym; sp->prev_dec = s.prev_dec;
-        sp->buf[0] = b0; sp->buf[1] = b1; sp->buf[2] = b2; sp->buf[3] = b3;
-        sp->buf_idx = 3;
-        a.counts[c] = count;
+    if (wave == 0 && lane == 0) { sp->c_phase = cl.phase; sp->c_freq = cl.freq; }
+    if (wave == 1) {
+        if (lane == 0) {
+            sp->t_phase = s.t_phase; sp->t_integ = s.t_integ;
+            sp->prev_sym = s.prev_sym; sp->prev_dec = s.prev_dec;
+            sp->buf_idx = 3;
+            a.counts[c] = count;
+        }
+        // the last four rotated samples (oldest first) are the carried buffer
+        if (lane >= 60) sp->buf[lane - 60] = make_double2(pcr, pci);
+    }
+#undef CQ_RL
+}
+
+// pi/4-DQPSK differential decode (cqpsk.py:308-350) of the symbols k_cq_seq produced, one thread per symbol: the phase
+// of a symbol and of its predecessor (the carried prev_phase for the first), the difference wrapped and rounded to a
+// multiple of pi / 4.  Nothing feeds back, so it is no part of the sequential kernel.
+__global__ __launch_bounds__(256) void k_cq_decode(CqArgs a) {
+    const int c = blockIdx.x, tid = threadIdx.x;
+    CqState *const sp = a.st + c;
+    const double2 *sym = a.symbols ? a.symbols + (size_t)c * a.cap : a.symws + (size_t)c * a.symcap;
+    uint8_t *dib = a.dibits + (size_t)c * a.cap;
+    const int count = a.counts[c];
+    const double carried = sp->prev_phase;
+    const double inv_q = 1.0 / (PI_D / 4);
+    __syncthreads();                               // every thread has the carried phase before it is replaced
+    for (int i = tid; i < count; i += 256) {
+        const double2 v = sym[i];
+        const double p = cq_atan2(v.y, v.x);
+        double pp = carried;
+        if (i > 0) { const double2 u = sym[i - 1]; pp = cq_atan2(u.y, u.x); }
+        double dp = DS(p, pp);
+        dp = dp > PI_D ? DS(dp, 2 * PI_D) : dp;
+        dp = dp < -PI_D ? DA(dp, 2 * PI_D) : dp;
+        long long idx = (long long)rint(DM(DA(dp, PI_D), inv_q));
+        idx &= 7;                                  // == ((idx % 8) + 8) % 8 in two's complement
+        dib[i] = (uint8_t)(idx >> 1);
+        if (i == count - 1) sp->prev_phase = p;
     }
 }
 
@@ -253,33 +361,19 @@ struct CostasState { double phase, freq; };
 __global__ __launch_bounds__(64) void k_costas(const double2 *x, size_t stride, int n, CostasState *st, double kp,
                                                double ki, double maxf, double2 *out, size_t out_stride) {
     const int c = blockIdx.x, lane = threadIdx.x;
-    double phase = st[c].phase, freq = st[c].freq;
+    CqCostas cl{st[c].phase, st[c].freq};
     const double2 *xc = x + (size_t)c * stride;
     double2 *oc = out + (size_t)c * out_stride;
-    const double q = PI_D / 4, inv_q = 1.0 / (PI_D / 4);
     for (int t0 = 0; t0 < n; t0 += 64) {
         const double2 xl = t0 + lane < n ? xc[t0 + lane] : make_double2(0.0, 0.0);
         const int m = n - t0 < 64 ? n - t0 : 64;
-        double2 mine = make_double2(0.0, 0.0);
-        for (int j = 0; j < m; ++j) {
-            const int xlo = __builtin_amdgcn_readlane(__double2loint(xl.x), j), xhi = __builtin_amdgcn_readlane(__double2hiint(xl.x), j);
-            const int ylo = __builtin_amdgcn_readlane(__double2loint(xl.y), j), yhi = __builtin_amdgcn_readlane(__double2hiint(xl.y), j);
-            const double xr = __hiloint2double(xhi, xlo), xi = __hiloint2double(yhi, ylo);
-            double sn, cs;
-            cq_sincos(phase, sn, cs);
-            const double cr = DS(DM(xr, cs), DM(xi, -sn));     // sample * exp(-j phase)
-            const double ci = DA(DM(xr, -sn), DM(xi, cs));
-            const double ph = cq_atan2(ci, cr);
-            const double err = DS(ph, DM(rint(DM(ph, inv_q)), q));   // (|err| <= pi/8: the reference's wrap never acts)
-            freq = fmin(fmax(DA(freq, DM(ki, err)), -maxf), maxf);
-            phase = DA(phase, DA(DM(kp, err), freq));
-            while (phase > PI_D) phase = DS(phase, 2 * PI_D);
-            while (phase < -PI_D) phase = DA(phase, 2 * PI_D);
-            if (lane == j) mine = make_double2(cr, ci);        // lane j keeps output j: one coalesced store per 64
-        }
-        if (t0 + lane < n) oc[t0 + lane] = mine;
+        const double phi = cq_costas_block(cl, cq_atan2(xl.y, xl.x), m, lane, kp, ki, maxf);   // (see k_cq_seq)
+        double sn, cs;
+        cq_sincos(phi, sn, cs);
+        if (t0 + lane < n)                                     // sample * exp(-j phi): one coalesced store per 64
+            oc[t0 + lane] = make_double2(DS(DM(xl.x, cs), DM(xl.y, -sn)), DA(DM(xl.x, -sn), DM(xl.y, cs)));
     }
-    if (lane == 0) { st[c].phase = phase; st[c].freq = freq; }
+    if (lane == 0) { st[c].phase = cl.phase; st[c].freq = cl.freq; }
 }
 
 struct MmState {
@@ -383,12 +477,17 @@ __global__ __launch_bounds__(64) void k_gardner(const float *x, size_t stride, i
 
 }  // namespace
 
+// symbols a call of n samples can produce: the Mueller-Muller period is clamped to [sps / 2, ...] (integrator within
+// +-sps / 4, symbol_timing.py:330-345), bound computed in floating point (sps / 2 need not be an integer)
+static size_t mm_symbol_bound(size_t n, double sps) { return (size_t)((double)n / (sps * 0.5)) + 2; }
+
 struct wh_cqpsk_bank {
     int C, n_max, L;
     double sps, c_kp, c_ki, c_maxf, t_kp, t_ki;
     std::vector<double> zi0;
     double *d_taps = nullptr;
-    double2 *d_state[2] = {nullptr, nullptr}, *d_full = nullptr;
+    double2 *d_state[2] = {nullptr, nullptr}, *d_full = nullptr, *d_symws = nullptr;
+    size_t symcap = 0;
     CqState *d_st = nullptr;
     int cur = 0;
 };
@@ -422,6 +521,8 @@ extern "C" int wh_cqpsk_bank_create(wh_cqpsk_bank **out, int C, double sps, cons
     WH_HIP(hipMemcpy(b->d_taps, taps.data(), ntaps * sizeof(double), hipMemcpyHostToDevice));
     for (int i = 0; i < 2; ++i) WH_HIP(hipMalloc(&b->d_state[i], (size_t)C * H * sizeof(double2)));
     WH_HIP(hipMalloc(&b->d_full, (size_t)C * (n_max + H) * sizeof(double2)));
+    b->symcap = mm_symbol_bound((size_t)n_max, sps);
+    WH_HIP(hipMalloc(&b->d_symws, (size_t)C * b->symcap * sizeof(double2)));
     WH_HIP(hipMalloc(&b->d_st, (size_t)C * sizeof(CqState)));
     int rc = cq_reset(b, nullptr);
     if (rc != WH_OK) return rc;
@@ -432,13 +533,13 @@ extern "C" int wh_cqpsk_bank_create(wh_cqpsk_bank **out, int C, double sps, cons
 extern "C" void wh_cqpsk_bank_destroy(wh_cqpsk_bank *b) {
     if (!b) return;
     (void)hipFree(b->d_taps); (void)hipFree(b->d_state[0]); (void)hipFree(b->d_state[1]); (void)hipFree(b->d_full);
+    (void)hipFree(b->d_symws);
     (void)hipFree(b->d_st);
     delete b;
 }
 
 // symbols a call of n samples can produce: the Mueller-Muller period is clamped to [sps / 2, ...] (integrator within
 // +-sps / 4, symbol_timing.py:330-345), bound computed in floating point (sps / 2 need not be an integer)
-static size_t mm_symbol_bound(size_t n, double sps) { return (size_t)((double)n / (sps * 0.5)) + 2; }
 
 // Grow the matched-filter workspace for calls of up to n_max samples per channel (never shrinks; no state lives in it).
 // Allocates and synchronises the stream: not for the hot path.
@@ -446,12 +547,17 @@ extern "C" int wh_cqpsk_bank_reserve(wh_cqpsk_bank *b, size_t n_max, void *strea
     if (!b) return set_err(WH_E_ARG, "wh_cqpsk_bank_reserve: null handle");
     if (n_max > (size_t)1 << 26) return set_err(WH_E_ARG, "wh_cqpsk_bank_reserve: more than 2^26 samples per call");
     if (n_max <= (size_t)b->n_max) return WH_OK;
-    double2 *full = nullptr;
+    double2 *full = nullptr, *symws = nullptr;
+    const size_t symcap = mm_symbol_bound(n_max, b->sps);
     WH_HIP(hipMalloc(&full, (size_t)b->C * (n_max + b->L - 1) * sizeof(double2)));
-    hipError_t e = hipStreamSynchronize(as_stream(stream));   // earlier calls may still read the old workspace
-    if (e != hipSuccess) { (void)hipFree(full); return set_err(WH_E_HIP, "wh_cqpsk_bank_reserve: %s", hipGetErrorString(e)); }
+    hipError_t e = hipMalloc(&symws, (size_t)b->C * symcap * sizeof(double2));
+    if (e == hipSuccess) e = hipStreamSynchronize(as_stream(stream));   // earlier calls may still read the old workspaces
+    if (e != hipSuccess) { (void)hipFree(full); (void)hipFree(symws); return set_err(WH_E_HIP, "wh_cqpsk_bank_reserve: %s", hipGetErrorString(e)); }
     (void)hipFree(b->d_full);
+    (void)hipFree(b->d_symws);
     b->d_full = full;
+    b->d_symws = symws;
+    b->symcap = symcap;
     b->n_max = (int)n_max;
     return WH_OK;
 }
@@ -485,12 +591,15 @@ extern "C" int wh_cqpsk_bank_run(wh_cqpsk_bank *b, const float *d_iq, size_t n, 
     a.t_maxdev = b->sps / 4;
     a.dibits = d_dibits;
     a.symbols = reinterpret_cast<double2 *>(d_symbols);
+    a.symws = b->d_symws; a.symcap = b->symcap;
     a.cap = cap;
     a.counts = d_counts;
     const int H = b->L - 1;
     hipLaunchKernelGGL(k_cq_rrc, dim3((unsigned)((n + H + 255) / 256), b->C), dim3(256), b->L * sizeof(double), st, a);
     WH_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_cq_seq, dim3((unsigned)b->C), dim3(64), 0, st, a);   // one wave per channel
+    hipLaunchKernelGGL(k_cq_seq, dim3((unsigned)b->C), dim3(128), 0, st, a);   // two waves per channel (carrier | timing)
+    WH_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_cq_decode, dim3((unsigned)b->C), dim3(256), 0, st, a);
     WH_LAUNCH_CHECK();
     b->cur ^= 1;
     return WH_OK;
