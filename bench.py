@@ -130,9 +130,10 @@ def cpu_baseline(seconds_budget: float = 8.0):
 
 def _profile_counter(kernel_substr: str, counter: str):
     """Average of a hardware counter per launch of a kernel, from the committed rocprofv3 summary of this round
-    (profiles/r02_pmc_bench.json, written by tools/pmc_run.sh + tools/pmc_summary.py); None when absent."""
+    (the newest profiles/rNN_pmc_bench.json, written by tools/pmc_run.sh + tools/pmc_to_profiles.py); None when absent."""
+    import glob
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_bench.json")))
+        d = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_bench.json")))[-1]))
     except Exception:
         return None
     for name, rec in d.items():
@@ -188,7 +189,7 @@ def _nbfm_valu(el: float, sample_channels: float):
     (1 reciprocal at quarter rate + ~8 polynomial ops = 12 slots) + 1001 taps / 50 = 20 real MACs per input sample
     (10 packed FMAs) = 36 issue slots per lane, i.e. 36 / 64 wave64 instructions; a wave64 instruction holds one of the
     1024 SIMDs for 4 cycles at <= 2.4 GHz.  Issue efficiency: SQ_INSTS_VALU of the shipped kernel, read from this round's
-    committed rocprofv3 summary (profiles/r02_pmc_bench.json), not a constant."""
+    committed rocprofv3 summary (the newest profiles/rNN_pmc_bench.json), not a constant."""
     slots = 36.0
     floor = sample_channels * slots / 64.0 * 4.0 / 1024.0 / 2.4e9
     out = {"algorithmic_valu_slots_per_sample_channel": slots, "algorithmic_valu_floor_ms": round(floor * 1e3, 3),
