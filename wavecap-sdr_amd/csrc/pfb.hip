@@ -1329,6 +1329,13 @@ extern "C" int wh_pfb_run_stats(wh_pfb *p, const void *d_iq, int input_format, s
             int gpw = 64;
             long long nwg = (n_groups + gpw - 1) / gpw;
             while (gpw > 2 && nwg < (long long)p->cu_count * 8) { gpw >>= 1; nwg = (n_groups + gpw - 1) / gpw; }
+            // nothing is stored, so nothing argues for short runs: one resident round (two workgroups per CU) of equal runs
+            // when the call is long enough -- a quarter of the workspace rows for the reduction to read (81 -> ~20 us)
+            if (nwg > 2LL * p->cu_count) {
+                nwg = 2LL * p->cu_count;
+                gpw = (int)((n_groups + nwg - 1) / nwg);
+                nwg = (n_groups + gpw - 1) / gpw;
+            }
             if (p->gpw_override > 0) { gpw = p->gpw_override; nwg = (n_groups + gpw - 1) / gpw; }
             a.groups_per_wg = gpw; a.n_wg = (int)nwg;
             a.max_block = (long long)(n / (size_t)FHOP) - 1;
