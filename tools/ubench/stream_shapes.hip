@@ -89,30 +89,35 @@ int main(int argc, char **argv) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    const int Rs[] = {4, 16, 64, 256};
-    for (int wide = 0; wide < 1; ++wide)
-        for (int xcd = 0; xcd < 2; ++xcd)
-            for (int occ = 1; occ <= 8; occ *= 2)
-                for (int R : Rs) {
-                    const int rot = 0, halo = 0;
-                    const size_t lds = occ == 8 ? 0 : (size_t)(160 * 1024 / occ) - 1024;
-                    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(walk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
-                    Args a{in, out, hops, R, rot, xcd, wide, halo};
-                    const long long runs = (hops + R - 1) / R;
-                    const unsigned grid = (unsigned)(((runs + 7) / 8) * 8);
-                    float best = 1e9f;
-                    for (int rep = 0; rep < 6; ++rep) {
-                        CK(hipEventRecord(e0));
-                        hipLaunchKernelGGL(walk_kernel, dim3(grid), dim3(256), lds, 0, a);
-                        CK(hipEventRecord(e1));
-                        CK(hipEventSynchronize(e1));
-                        float ms;
-                        CK(hipEventElapsedTime(&ms, e0, e1));
-                        if (rep > 0 && ms < best) best = ms;
-                    }
-                    printf("xcd=%d WGs/CU=%d R=%4d  %.4f ms  %.2f TB/s\n", xcd, occ, R, best,
-                           24.0 * (double)n / best * 1e-9);
-                    fflush(stdout);
-                }
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(walk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+    auto run = [&](int xcd, int occ, int halo, int R) {
+        Args a{in, out, hops, R, 0, xcd, 0, halo};
+        const long long runs = (hops + R - 1) / R;
+        const unsigned grid = (unsigned)(((runs + 7) / 8) * 8);
+        const size_t lds = occ >= 8 ? 0 : (size_t)(160 * 1024 / occ) - 1024;   // dynamic LDS only limits residency
+        float best = 1e9f;
+        for (int rep = 0; rep < 6; ++rep) {
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL(walk_kernel, dim3(grid), dim3(256), lds, 0, a);
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep > 0 && ms < best) best = ms;
+        }
+        printf("mapping=%s resident WGs/CU=%d halo re-reads=%d R=%4d hops  %.4f ms  %.2f TB/s (%.3f of 8)\n",
+               xcd ? "xcd-contiguous" : "linear", occ, halo, R, best, 24.0 * (double)n / best * 1e-9, 24.0 * (double)n / best * 1e-9 / 8.0);
+        fflush(stdout);
+    };
+    printf("# 1. run length x mapping, 8 resident workgroups per CU\n");
+    for (int xcd = 0; xcd < 2; ++xcd)
+        for (int R : {4, 8, 16, 32, 64, 128, 256, 1024}) run(xcd, 8, 0, R);
+    printf("# 2. the 9-block halo re-read per group (a workgroup without a carried window), 8 resident per CU\n");
+    for (int xcd = 0; xcd < 2; ++xcd)
+        for (int R : {4, 16, 64, 256}) run(xcd, 8, 1, R);
+    printf("# 3. resident workgroups per CU\n");
+    for (int xcd = 0; xcd < 2; ++xcd)
+        for (int occ : {1, 2, 4, 8})
+            for (int R : {4, 16, 64, 256}) run(xcd, occ, 0, R);
     return 0;
 }
