@@ -176,3 +176,23 @@ def test_config1_wbfm_10s_single_channel():
         ref, met = O.process_channel_wbfm(parts[c % 4], fs, 0.0)
         assert peak_rel_err(a[c, 0].cpu().numpy(), ref) <= 1e-5
         assert abs(float(m[c, 0, 0]) - met["rssi_db"]) <= 2e-4
+
+
+def test_plan_keeps_bits_and_history():
+    """PolyphaseChannelizer.plan(): every run length gives the same output bits and the same carried history; planning
+    restores the history it found and reports the candidates it timed."""
+    import torch
+    import wavehip
+
+    n = 1 << 22
+    g = torch.Generator(device="cuda").manual_seed(77)
+    x = torch.view_as_complex(torch.randn(n, 2, device="cuda", generator=g).mul_(0.5))
+    a, b = wavehip.PolyphaseChannelizer(10_000_000, 9765), wavehip.PolyphaseChannelizer(10_000_000, 9765)
+    a.process_device(x[: 1 << 16])
+    b.process_device(x[: 1 << 16])
+    hist = a.arm_history
+    best = a.plan(x, candidates=(0, 8, 32))
+    assert best in (0, 8, 32) and set(a.planned["median_ms"]) == {0, 8, 32}
+    assert np.array_equal(a.arm_history, hist)
+    ya, yb = a.process_device(x), b.process_device(x)
+    assert torch.equal(ya, yb) and np.array_equal(a.arm_history, b.arm_history)
