@@ -783,6 +783,31 @@ def gen_caprate():
     save("chain_caprate", **out)
 
 
+def gen_zero():
+    """FM chains on input with EXACT zero samples (tests/signals.nbfm_zero_gap_i16): the discriminator value of a sample
+    whose conjugate product is exactly zero hangs on IEEE signed zeros in the reference (numpy's complex64 product of a
+    zero sample with the mixer phase, then np.angle = arctan2: (+-0, -0) -> +-pi) -- pinned here from the reference itself."""
+    fs, n = 2400000, 120000
+    i16 = S.nbfm_zero_gap_i16(n, fs)
+    z = i16.astype(np.float32) / 32768.0
+    z = (z[0::2] + 1j * z[1::2]).astype(np.complex64)
+    out = {"sha_i16": np.array(S.sha256(i16)), "args": np.array([fs, n], dtype=np.int64)}
+    offs = [S.nbfm_bank_offsets(32)[k] for k in (12, 15)] + [0.0]
+    for k, off in enumerate(offs):
+        rc._get_freq_shift_exp.cache_clear()
+        audio, met = rc._process_channel_dsp_stateless(z, fs, _cfg("nbfm", off))
+        out[f"nbfm{k}_off"] = np.array([off])
+        out[f"nbfm{k}_audio"] = audio
+        out[f"nbfm{k}_met"] = np.array([met["rssi_db"], met["signal_power_db"]])
+        fm = rfm.quadrature_demod(z if off == 0.0 else rc.freq_shift(z, off, fs), fs)
+        print(f"  zero case nbfm off={off}: discriminator of the muted stretch takes values {np.unique(np.round(fm[30001:30600], 3))[:6]}")
+    rc._get_freq_shift_exp.cache_clear()
+    audio, met = rc._process_channel_dsp_stateless(z, fs, rc.ChannelConfig(id="w", capture_id="c", mode="wbfm", offset_hz=200000.0))
+    out["wbfm_audio"] = audio
+    out["wbfm_met"] = np.array([met["rssi_db"], met["signal_power_db"]])
+    save("chain_zero", **out)
+
+
 def gen_blanker():
     """A14: noise_blanker (dsp/filters.py:267-343) on float32 audio with impulses; even and odd lengths."""
     from wavecapsdr.dsp.filters import noise_blanker
@@ -952,7 +977,7 @@ def gen_lsm():
     save("lsm", **out)
 
 
-ALL = dict(caprate=gen_caprate, c4fm_big=gen_c4fm_big, cqpsk_big=gen_cqpsk_big, status=gen_status, cqpsk_parts=gen_cqpsk_parts, chain4=gen_chain4, blanker=gen_blanker, nid=gen_nid, classifier=gen_classifier, recorder=gen_recorder, nr=gen_nr, sam=gen_sam, rawdig=gen_rawdig, lsm=gen_lsm, framer=gen_framer, cqpsk=gen_cqpsk, trunk=gen_trunk, a1=gen_a1, a2=gen_a2, a3=gen_a3, a6=gen_a6, chain=gen_chain, a7=gen_a7, a8=gen_a8, c4fm=gen_c4fm)
+ALL = dict(zero=gen_zero, caprate=gen_caprate, c4fm_big=gen_c4fm_big, cqpsk_big=gen_cqpsk_big, status=gen_status, cqpsk_parts=gen_cqpsk_parts, chain4=gen_chain4, blanker=gen_blanker, nid=gen_nid, classifier=gen_classifier, recorder=gen_recorder, nr=gen_nr, sam=gen_sam, rawdig=gen_rawdig, lsm=gen_lsm, framer=gen_framer, cqpsk=gen_cqpsk, trunk=gen_trunk, a1=gen_a1, a2=gen_a2, a3=gen_a3, a6=gen_a6, chain=gen_chain, a7=gen_a7, a8=gen_a8, c4fm=gen_c4fm)
 
 if __name__ == "__main__":
     import logging

@@ -78,6 +78,16 @@ def nbfm_bank_offsets(n_ch: int = 32, spacing: float = 50_000.0) -> list[float]:
     return [float((k - (n_ch - 1) / 2.0) * spacing) for k in range(n_ch)]
 
 
+def nbfm_zero_gap_i16(n: int = 120_000, fs: int = 2_400_000, seed: int = 77) -> np.ndarray:
+    """Config-2 content as int16 IQ with EXACT zero samples: 600 muted samples and four isolated ones (zero-fill after an
+    overflow, muted front ends)."""
+    i16 = pack_iq16_np(nbfm_bank_c64(n, fs, seed=seed)).copy()
+    i16[2 * 30000:2 * 30600] = 0
+    for k in (5, 5000, 70001, n - 1):
+        i16[2 * k:2 * k + 2] = 0
+    return i16
+
+
 def pack_iq16_np(x: np.ndarray) -> np.ndarray:
     """Reference wire rule (capture.py:102-116): clip(-1,1)*32767 -> astype(int16)."""
     f = np.ascontiguousarray(x.astype(np.complex64)).view(np.float32).copy()

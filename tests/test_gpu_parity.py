@@ -616,6 +616,43 @@ def test_chain_am_ssb_sam_at_capture_rates(wh, golden):
     assert n_audio >= 5
 
 
+def test_chain_fm_exact_zero_samples(wh, O, golden):
+    """Muted input (a stretch of exact zeros, isolated zero samples): the reference's discriminator value of a sample whose
+    conjugate product is exactly zero hangs on IEEE signed zeros -- numpy's complex product of a zero sample with the mixer
+    phase gives (+-0, +-0) by the phase's quadrant, and np.angle = arctan2 maps (+-0, -0) to +-pi -- so a muted stretch
+    comes out as 0 or +-pi x scale.  NBFM (the fused kernel: raw angles + mixer step, zero products evaluated by
+    fm_single_zero) and WBFM (the unfused front) against the numpy oracle, which inherits numpy's semantics; int16 and
+    complex64 input.  (Round 2 returned 0 for such samples: up to 0.2 of peak off on this input.)"""
+    fs, n = 2_400_000, 120_000
+    offs = S.nbfm_bank_offsets(32)[12:16]
+    i16 = S.nbfm_zero_gap_i16(n, fs)
+    z = i16.astype(np.float32) / 32768.0
+    z = (z[0::2] + 1j * z[1::2]).astype(np.complex64)
+    cfgs = [_nbfm_cfg(wh, o) for o in offs] + [_nbfm_cfg(wh, 0.0)]
+    for fmt, src in (("int16", i16), ("cf32", z)):
+        res = wh.ChannelBank(fs, n, cfgs, input_format=fmt).process(src)
+        for k, cfg in enumerate(cfgs):
+            a_ref, m_ref = O.process_channel_nbfm(z, fs, float(cfg.offset_hz))
+            a, m = res[k]
+            assert (a is None) == (a_ref is None), (fmt, k)
+            if a is not None:
+                assert peak_rel_err(a, a_ref) <= TOL, (fmt, k)
+            assert db_close(m["rssi_db"], m_ref["rssi_db"]), (fmt, k)
+    w = wh.ChannelConfig(mode="wbfm", offset_hz=200000.0)
+    a, m = wh.process_channel_dsp_stateless(z, fs, w)
+    a_ref, m_ref = O.process_channel_wbfm(z, fs, 200000.0)
+    assert (a is None) == (a_ref is None)
+    if a is not None:
+        assert peak_rel_err(a, a_ref) <= TOL
+    # ... and against the reference itself (tests/golden/chain_zero.npz: its discriminator of the muted stretch is 0 / 16)
+    g = golden("chain_zero")
+    assert S.sha256(i16) == str(g["sha_i16"])
+    for k in range(3):
+        au, me = wh.process_channel_dsp_stateless(z, fs, _nbfm_cfg(wh, float(g[f"nbfm{k}_off"][0])))
+        assert peak_rel_err(au, g[f"nbfm{k}_audio"]) <= TOL and db_close([me["rssi_db"], me["signal_power_db"]], g[f"nbfm{k}_met"]), k
+    assert peak_rel_err(a, g["wbfm_audio"]) <= TOL and db_close([m["rssi_db"], m["signal_power_db"]], g["wbfm_met"])
+
+
 def test_chain_spectral_noise_reduction(wh, golden):
     """enable_noise_reduction on the FM chains (dsp/filters.py:346-460): STFT / percentile floor / Wiener gain /
     ISTFT on the device; audio length follows the shortened row; < 1024-sample chunks pass through.

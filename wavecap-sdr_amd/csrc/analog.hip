@@ -177,6 +177,8 @@ struct FmArgs {
     const float *nco_c; // [K] f32(-2 pi off/fs); 0 => no mix
     const double *taps; // [ntaps]
     int fmt, N, K, n_out, ntaps, down, d0, TO, R;   // R: output tiles per workgroup (fused kernel)
+    const float *araw;      // fused kernel, fast front: [n_chunks][N] raw discriminator angles (fm_rawdisc_kernel); NaN where the
+                            // sample pair's product is exactly zero; nullptr = the per-channel front of round 2
     const float2 *tphase;   // fir_phase: float2 [21][32] = the tap pairs (trev[q down + 2 rp], trev[.. + 1]) by block and phase pair
     int fir_phase;      // fused kernel: != 0 -> the decimating FIR runs in its polyphase register form (fm_fir_phases), TO = 128
     float scale;        // fs / (2 pi 75000)
@@ -219,6 +221,35 @@ __device__ __forceinline__ fm_v2f fast_atan2f_x2(fm_v2f y, fm_v2f x) {
     r.x = x.x < 0.0f ? PI_F - r.x : r.x;
     r.y = x.y < 0.0f ? PI_F - r.y : r.y;
     return fm_v2f{__builtin_copysignf(r.x, y.x), __builtin_copysignf(r.y, y.y)};
+}
+
+// A sample whose conjugate product with its predecessor is EXACTLY zero (a zero sample: muted input, overflow recovery
+// returning zero buffers): the reference's discriminator value then hangs on the SIGNS of zeros -- numpy mixes with
+// (xr c - xi s, xr s + xi c), multiplies by the conjugate as (ar br - ai bi', ar bi' + ai br) with bi' = -bi, single
+// roundings, and np.angle is arctan2, which maps (+-0, -0) to +-pi: a muted stretch comes out as 0 or +-pi x scale
+// depending on the quadrant of the mixer phase.  Reproduced here operation for operation (the magnitudes are zero; only
+// the IEEE sign rules act).  Rare and per sample, so the value never depends on the pass that computes it.
+template <int FMT, bool MIX>
+__device__ __forceinline__ float fm_single_zero(const FmArgs &a, size_t in_base, int n, float c) {
+    const float PI_F = 3.14159265358979323846f;
+    const float2 xp = load_iq(a.in, FMT, in_base + n - 1), xc = load_iq(a.in, FMT, in_base + n);
+    float2 bp = xp, bc = xc;
+    if (MIX) {
+        const fm_v2f C_HI = {0.15915494f, 0.15915494f}, C_LO = {6.4206382e-09f, 6.4206382e-09f};
+        const fm_v2f ph = fm_v2f{c, c} * fm_v2f{(float)(n - 1), (float)n};
+        const fm_v2f t_hi = ph * C_HI;
+        const fm_v2f t_lo = __builtin_elementwise_fma(ph, C_LO, __builtin_elementwise_fma(ph, C_HI, -t_hi));
+        const fm_v2f fr = fm_v2f{__builtin_amdgcn_fractf(t_hi.x), __builtin_amdgcn_fractf(t_hi.y)} + t_lo;
+        const float sp = __builtin_amdgcn_sinf(fr.x), cp = __builtin_amdgcn_cosf(fr.x);
+        const float sc = __builtin_amdgcn_sinf(fr.y), cc = __builtin_amdgcn_cosf(fr.y);
+        bp = make_float2(__fsub_rn(__fmul_rn(xp.x, cp), __fmul_rn(xp.y, sp)), __fadd_rn(__fmul_rn(xp.x, sp), __fmul_rn(xp.y, cp)));
+        bc = make_float2(__fsub_rn(__fmul_rn(xc.x, cc), __fmul_rn(xc.y, sc)), __fadd_rn(__fmul_rn(xc.x, sc), __fmul_rn(xc.y, cc)));
+    }
+    const float nbi = -bp.y;
+    const float re = __fsub_rn(__fmul_rn(bc.x, bp.x), __fmul_rn(bc.y, nbi));
+    const float im = __fadd_rn(__fmul_rn(bc.x, nbi), __fmul_rn(bc.y, bp.x));
+    if (re == 0.0f && im == 0.0f) return __builtin_signbitf(re) ? __builtin_copysignf(PI_F, im) : __builtin_copysignf(0.0f, im);
+    return fast_atan2f_x2(fm_v2f{im, im}, fm_v2f{re, re}).x;
 }
 
 // Phase 1 of the fused kernel, TWO samples per lane: lane l of a wave takes the window indices s0 + 2l - 1 and s0 + 2l (a
@@ -287,6 +318,9 @@ __device__ __forceinline__ void fm_phase1(const FmArgs &a, float *fm_s, int i_lo
         const fm_v2f re = __builtin_elementwise_fma(bx, px, by * py);
         const fm_v2f im = __builtin_elementwise_fma(by, px, -(bx * py));
         fm_v2f v = fast_atan2f_x2(im, re) * fm_v2f{a.scale, a.scale};
+        // exactly-zero products: the reference's signed-zero result (fm_single_zero), per sample
+        if (lane > 0 && re.x == 0.f && im.x == 0.f && va && na >= 1) v.x = fm_single_zero<FMT, MIX>(a, in_base, na, c) * a.scale;
+        if (re.y == 0.f && im.y == 0.f && vb && nb >= 1) v.y = fm_single_zero<FMT, MIX>(a, in_base, nb, c) * a.scale;
         if (CHECK) {
             if (!(va && na >= 1)) v.x = 0.f;
             if (!(vb && nb >= 1)) v.y = 0.f;
@@ -308,6 +342,103 @@ __device__ __forceinline__ void fm_phase1(const FmArgs &a, float *fm_s, int i_lo
     }
     p_base += (double)(sb_a + sb_b);
     p_fm += (double)(sf_a + sf_b);
+}
+
+// ---- the FM front without per-channel transcendentals ---------------------------------------------------------------
+// The discriminator of a MIXED channel is the discriminator of the RAW stream plus the mixer's phase step:
+//     angle(b[n] conj b[n-1]),  b[n] = x[n] e^{j phi_n}   =   wrap( angle(x[n] conj x[n-1]) + (phi_n - phi_{n-1}) )
+// exactly, and the reference's mixer phase is phi_n = float32(c) * float32(n) (capture.py:173-176), whose consecutive
+// values differ by an exactly representable float32 (Sterbenz).  So the raw angles a[n] are taken ONCE per chunk
+// (fm_rawdisc_kernel: the discriminator arithmetic of fm_phase1 on the unmixed samples) and a channel's front is
+//     v = scale * wrap(a[n] + (fl(c n) - fl(c (n - 1))))
+// -- two multiplies, a subtraction, an addition and a wrap instead of sincos, mixing, the conjugate product and an
+// arctangent per sample AND channel (~90 -> ~25 issue slots per pair).  Against the reference this moves the rounding of
+// the mixed products into the rounding of a[n] (both ~1e-7 rad; audio of the NBFM goldens: 1.1e-7 .. 2.4e-7 of peak by
+// this route in numpy, 0.6e-7 .. 1.5e-7 by the reference's own order).  Where a sample pair's product is EXACTLY zero
+// (a zero sample: the reference's result then hangs on signed zeros of the mixed values) a[n] is NaN and that sample
+// alone is evaluated by fm_single_zero.
+template <int FMT>
+__global__ __launch_bounds__(256) void fm_rawdisc_kernel(FmArgs a, float *araw) {
+    const int chunk = blockIdx.y, tid = threadIdx.x;
+    const int N = a.N;
+    const size_t in_base = (size_t)chunk * N;
+    float pw = 0.f;
+    for (int n0 = blockIdx.x * 1024; n0 < N; n0 += gridDim.x * 1024) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int n = n0 + u * 256 + tid;
+            if (n >= N) continue;
+            const float2 x = load_iq(a.in, FMT, in_base + n);
+            float v = 0.f;                                     // dsp/fm.py:94: out[0] = 0
+            if (n > 0) {
+                const float2 p = load_iq(a.in, FMT, in_base + n - 1);
+                const float re = fmaf(x.x, p.x, x.y * p.y), im = fmaf(x.y, p.x, -(x.x * p.y));   // fm_phase1's products
+                const fm_v2f r = fast_atan2f_x2(fm_v2f{im, im}, fm_v2f{re, re});
+                v = (re == 0.0f && im == 0.0f) ? __int_as_float(0x7fc00000) : r.x;
+            }
+            araw[in_base + n] = v;
+            pw += fmaf(x.x, x.x, x.y * x.y);
+        }
+    }
+    // sum |x|^2 of the chunk -> channel 0's slot (shared by the chunk's channels, see fmbank_finalize_kernel)
+    __shared__ double red[4];
+    double d = (double)pw;
+    for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+    if ((tid & 63) == 0) red[tid >> 6] = d;
+    __syncthreads();
+    if (tid == 0) atomicAdd(a.acc + (size_t)chunk * a.K * 2, red[0] + red[1] + red[2] + red[3]);
+}
+
+// the fast front over window indices [i_lo, i_hi): lane l takes the pair i_lo + 128 (wave + 4 k) + 2 l, + 1; the float32
+// sums of v^2 as in fm_phase1.  CHECK: passes at the chunk's edges (samples outside [0, N) are zeros, sample 0 has no
+// predecessor: v = 0, dsp/fm.py:94) and ownership masks for the sums -- the SAME formula as the interior passes, so that a
+// sample's value never depends on which pass computes it.
+template <bool CHECK, int FMT, bool MIX>
+__device__ __forceinline__ void fm_phase1_fast(const FmArgs &a, float *fm_s, int i_lo, int i_hi, int n_lo, int N, float c,
+                                               size_t in_base, int own_lo, int own_hi, int lane, int wave, double &p_fm,
+                                               const bool sums) {
+    const float *ar = a.araw + in_base;
+    const float INV2PI = 0.15915494309189535f, TWOPI = 6.283185307179586f;
+    float sf_a = 0.f, sf_b = 0.f;
+    for (int s0 = i_lo + wave * 128; s0 < i_hi; s0 += 4 * 128) {
+        const int ia = s0 + 2 * lane, ib = ia + 1;
+        const int na = n_lo + ia, nb = na + 1;
+        const bool oka = ia < i_hi, okb = ib < i_hi;
+        const bool va = !CHECK || (na >= 1 && na < N), vb = !CHECK || (nb >= 1 && nb < N);
+        int la = oka ? na : n_lo + i_hi - 1, lb = okb ? nb : n_lo + i_hi - 1;
+        if (CHECK) {
+            la = la < 0 ? 0 : (la > N - 1 ? N - 1 : la);
+            lb = lb < 0 ? 0 : (lb > N - 1 ? N - 1 : lb);
+        }
+        const float aa = ar[la], ab = ar[lb];
+        fm_v2f s = {aa, ab};
+        if (MIX) {
+            // phi_n - phi_{n-1} with phi_n = fl(c n): single roundings, no contraction (an FMA here would be the exact c)
+            const float naf = (float)na;
+            const float pm = __fmul_rn(c, naf - 1.0f), pa = __fmul_rn(c, naf), pb = __fmul_rn(c, naf + 1.0f);
+            s = s + fm_v2f{__fsub_rn(pa, pm), __fsub_rn(pb, pa)};
+        }
+        const fm_v2f t = s * fm_v2f{INV2PI, INV2PI};
+        const fm_v2f r = {__builtin_rintf(t.x), __builtin_rintf(t.y)};
+        s = __builtin_elementwise_fma(r, fm_v2f{-TWOPI, -TWOPI}, s);          // into [-pi, pi]
+        fm_v2f v = s * fm_v2f{a.scale, a.scale};
+        // a sample whose raw product is exactly zero (NaN marker): the reference's signed-zero result for that sample alone
+        if (oka && va && aa != aa) v.x = fm_single_zero<FMT, MIX>(a, in_base, na, c) * a.scale;
+        if (okb && vb && ab != ab) v.y = fm_single_zero<FMT, MIX>(a, in_base, nb, c) * a.scale;
+        if (CHECK) {
+            if (!va) v.x = 0.f;
+            if (!vb) v.y = 0.f;
+        }
+        if (oka) {
+            fm_s[ia] = v.x;
+            if (!CHECK || (na >= own_lo && na < own_hi)) sf_a = fmaf(v.x, v.x, sf_a);
+        }
+        if (okb) {
+            fm_s[ib] = v.y;
+            if (!CHECK || (nb >= own_lo && nb < own_hi)) sf_b = fmaf(v.y, v.y, sf_b);
+        }
+    }
+    if (sums) p_fm += (double)(sf_a + sf_b);
 }
 
 // ---- phase 2 in polyphase register form ---------------------------------------------------------------------------
@@ -391,6 +522,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) voi
     // produce the whole window, but its part [0, keep) belongs to earlier tiles -- so it is made by a pass of its own
     // that sums nothing, and every sample is summed by the same pass with the same step grid wherever the row is cut.
     const int dlt = keep > 0 ? a.d0 + 1 - a.down : 0;
+    // (always the case for resample_poly's designs: ntaps = 20 down + 1, d0 = 10 down -> dlt = 9 down + 1, keep = 19 down + 1;
+    // a design outside that keeps the round-2 rule: owned = [t_lo adv, t_hi adv), sums then depend on the cut at 1e-8)
     const bool split_first = keep > 0 && dlt >= 0 && dlt <= keep;
     const int own_lo = t_lo == 0 ? 0 : (split_first ? t_lo * adv + dlt : t_lo * adv);
     const int own_hi = t_hi >= n_tiles ? N : (split_first ? t_hi * adv + dlt : t_hi * adv);   // exclusive
@@ -431,17 +564,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) voi
         // interior: every sample this pass touches (incl. lane 0's predecessor sample and the idle lanes of its last
         // 127-sample step) exists, every sample it stores is owned and has a predecessor
         const bool interior = n_lo + i_lo >= (own_lo > 1 ? own_lo : 1) && n_lo + W <= own_hi && n_lo + W + 128 <= N;
-        const bool base = k == 0;
+        const bool fast = a.araw != nullptr;           // raw angles taken once per chunk (fm_rawdisc_kernel, with sum |x|^2)
+        const bool base = k == 0 && !fast;
 #define WH_P1X(CHK, F, M, LO, HI, OL, OH, PB, PF) \
     fm_phase1<CHK, F, M>(a, fm_s, LO, HI, n_lo, N, c, in_base, OL, OH, lane, wave, PB, PF, base)
 #define WH_P1(CHK, F, M) WH_P1X(CHK, F, M, i_lo, W, own_lo, own_hi, p_base, p_fm)
+#define WH_P1F(CHK, F, M, LO, HI, OL, OH, PF, SUMS) \
+    fm_phase1_fast<CHK, F, M>(a, fm_s, LO, HI, n_lo, N, c, in_base, OL, OH, lane, wave, PF, SUMS)
         if (head) {
             // the carried part of the window, owned by earlier runs: computed, not summed (empty ownership range; its sums
             // go to scratch variables)
             double nb_ = 0.0, nf_ = 0.0;
             const bool in_a = n_lo >= 1 && n_lo + keep + 128 <= N;
 #define WH_P1A(CHK, F, M) WH_P1X(CHK, F, M, 0, keep, 0, 0, nb_, nf_)
-            if (in_a) {
+            if (fast) {
+                if (in_a) {
+                    if (a.fmt == 1) { if (do_mix) WH_P1F(false, 1, true, 0, keep, 0, 0, nf_, false); else WH_P1F(false, 1, false, 0, keep, 0, 0, nf_, false); }
+                    else            { if (do_mix) WH_P1F(false, 0, true, 0, keep, 0, 0, nf_, false); else WH_P1F(false, 0, false, 0, keep, 0, 0, nf_, false); }
+                } else {
+                    if (a.fmt == 1) { if (do_mix) WH_P1F(true, 1, true, 0, keep, 0, 0, nf_, false); else WH_P1F(true, 1, false, 0, keep, 0, 0, nf_, false); }
+                    else            { if (do_mix) WH_P1F(true, 0, true, 0, keep, 0, 0, nf_, false); else WH_P1F(true, 0, false, 0, keep, 0, 0, nf_, false); }
+                }
+            } else if (in_a) {
                 if (a.fmt == 1) { if (do_mix) WH_P1A(false, 1, true); else WH_P1A(false, 1, false); }
                 else            { if (do_mix) WH_P1A(false, 0, true); else WH_P1A(false, 0, false); }
             } else {
@@ -459,6 +603,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) voi
                 const int n = n_lo + i;
                 fm_s[i] = (n >= 0 && n < N) ? rw[n] : 0.0f;
             }
+        } else if (fast) {
+            if (interior) {
+                if (a.fmt == 1) { if (do_mix) WH_P1F(false, 1, true, i_lo, W, own_lo, own_hi, p_fm, true); else WH_P1F(false, 1, false, i_lo, W, own_lo, own_hi, p_fm, true); }
+                else            { if (do_mix) WH_P1F(false, 0, true, i_lo, W, own_lo, own_hi, p_fm, true); else WH_P1F(false, 0, false, i_lo, W, own_lo, own_hi, p_fm, true); }
+            } else {
+                if (a.fmt == 1) { if (do_mix) WH_P1F(true, 1, true, i_lo, W, own_lo, own_hi, p_fm, true); else WH_P1F(true, 1, false, i_lo, W, own_lo, own_hi, p_fm, true); }
+                else            { if (do_mix) WH_P1F(true, 0, true, i_lo, W, own_lo, own_hi, p_fm, true); else WH_P1F(true, 0, false, i_lo, W, own_lo, own_hi, p_fm, true); }
+            }
         } else if (interior) {
             if (a.fmt == 1) { if (do_mix) WH_P1(false, 1, true); else WH_P1(false, 1, false); }
             else            { if (do_mix) WH_P1(false, 0, true); else WH_P1(false, 0, false); }
@@ -468,6 +620,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) voi
         }
 #undef WH_P1
 #undef WH_P1X
+#undef WH_P1F
         __syncthreads();  // window (and, first time, taps) visible
 
         // phase 2: y[m0+o] = sum_i fm_s[o*down + i] * trev[i].
@@ -572,7 +725,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) voi
     __syncthreads();
     if (tid == 0) {
         double *acc = a.acc + ((size_t)chunk * a.K + k) * 2;
-        if (k == 0) atomicAdd(acc, red[0] + red[1] + red[2] + red[3]);   // shared by the chunk's channels (finalize)
+        if (k == 0 && a.araw == nullptr) atomicAdd(acc, red[0] + red[1] + red[2] + red[3]);   // shared by the chunk's channels (finalize); the fast front's pre-pass owns it
         atomicAdd(acc + 1, red[4] + red[5] + red[6] + red[7]);
     }
 }
@@ -1778,6 +1931,7 @@ struct wh_chanbank {
     int start_ep = 0;               // row length of d_G / d_S0: the chain's state count rounded up to even
     double *d_acc = nullptr;
     float *d_fm = nullptr;
+    float *d_araw = nullptr;   // fused FM path: raw discriminator angles of the call's chunks [n_chunks][N]
     size_t cap_chunks = 0;
     bool fused = false;
     bool rows_fir = false;   // unfused chain whose resampler is the fused kernel's decimating FIR
@@ -2012,6 +2166,7 @@ extern "C" void wh_chanbank_destroy(wh_chanbank *b) {
     (void)hipFree(b->d_taps);
     (void)hipFree(b->d_acc);
     (void)hipFree(b->d_fm);
+    (void)hipFree(b->d_araw);
     (void)hipFree(b->d_nr_win); (void)hipFree(b->d_nr_tw); (void)hipFree(b->d_nr_mag); (void)hipFree(b->d_nr_sel);
     (void)hipFree(b->d_nr_stft);
     delete b;
@@ -2047,9 +2202,12 @@ extern "C" int wh_chanbank_run_wire(wh_chanbank *b, const void *d_in, size_t n_c
         WH_HIP(hipStreamSynchronize(st));
         (void)hipFree(b->d_acc);
         (void)hipFree(b->d_fm);
+        (void)hipFree(b->d_araw);
         b->d_acc = nullptr;
         b->d_fm = nullptr;
+        b->d_araw = nullptr;
         WH_HIP(hipMalloc(&b->d_acc, rows * 2 * sizeof(double)));
+        if (b->fused) WH_HIP(hipMalloc(&b->d_araw, n_chunks * (size_t)c.chunk_len * sizeof(float)));
         if (!b->fused && (resample || b->nr)) WH_HIP(hipMalloc(&b->d_fm, rows * (size_t)c.chunk_len * sizeof(float)));
         if (b->d_G) {
             (void)hipFree(b->d_S0);
@@ -2089,6 +2247,7 @@ extern "C" int wh_chanbank_run_wire(wh_chanbank *b, const void *d_in, size_t n_c
     a.TO = b->TO;
     a.fir_phase = b->fir_phase;
     a.tphase = b->d_tphase;
+    a.araw = nullptr;
     a.R = 1;
     a.scale = (float)((double)c.sample_rate / (2.0 * M_PI * 75000.0));
     a.demod = c.demod;
@@ -2097,6 +2256,14 @@ extern "C" int wh_chanbank_run_wire(wh_chanbank *b, const void *d_in, size_t n_c
     a.pll_alpha = c.pll_alpha;
     a.pll_beta = c.pll_beta;
     if (b->fused) {
+        // raw discriminator angles + sum |x|^2, once per chunk (shared by the channels)
+        {
+            const unsigned gx = (unsigned)((c.chunk_len + 4095) / 4096);
+            if (c.input_format == 1) hipLaunchKernelGGL(fm_rawdisc_kernel<1>, dim3(gx, (unsigned)n_chunks), dim3(256), 0, st, a, b->d_araw);
+            else hipLaunchKernelGGL(fm_rawdisc_kernel<0>, dim3(gx, (unsigned)n_chunks), dim3(256), 0, st, a, b->d_araw);
+            WH_LAUNCH_CHECK();
+            a.araw = b->d_araw;
+        }
         const int tiles = (c.n_out + b->TO - 1) / b->TO;
         const int R = run_tiles(tiles, rows);
         a.R = R;
@@ -2250,7 +2417,7 @@ extern "C" int wh_channel_signal_metrics(const void *d_in, int input_format, siz
     WH_HIP(hipMemsetAsync(d_acc, 0, (size_t)K * 2 * sizeof(double), st));
     FmArgs a;
     a.in = d_in; a.audio = nullptr; a.acc = d_acc; a.fm_out = d_rows; a.rows_src = nullptr; a.skip_fm_sum = 0; a.nco_c = d_nco; a.taps = nullptr;
-    a.fmt = input_format; a.N = (int)n; a.K = K; a.n_out = 0; a.ntaps = 0; a.down = 1; a.d0 = 0; a.TO = 1; a.R = 1; a.fir_phase = 0; a.tphase = nullptr;
+    a.fmt = input_format; a.N = (int)n; a.K = K; a.n_out = 0; a.ntaps = 0; a.down = 1; a.d0 = 0; a.TO = 1; a.R = 1; a.fir_phase = 0; a.tphase = nullptr; a.araw = nullptr;
     a.scale = 0.f; a.demod = 1; a.bfo_c = 0.0; a.fs_d = (double)sample_rate; a.pll_alpha = a.pll_beta = 0.0;
     const int per_block = 4 * 63 * 16;
     hipLaunchKernelGGL(chan_front_kernel, dim3((unsigned)((n + per_block - 1) / per_block), K, 1), dim3(256), 0, st, a);

@@ -676,7 +676,8 @@ static int c4fm_resize(wh_c4fm_bank *b, int n_max, hipStream_t st) {
         C4_TRY(hipMemsetAsync(y, 0, (size_t)C * (Hy + n_max) * sizeof(double2), st));
         C4_TRY(hipMemsetAsync(z, 0, (size_t)C * (Hz + n_max) * sizeof(float2), st));
     }
-    C4_TRY(hipStreamSynchronize(st));   // earlier calls on this stream may still use the old workspaces
+    C4_TRY(hipStreamSynchronize(st));   // the copies above
+    C4_TRY(hipDeviceSynchronize());     // earlier calls (on whichever stream) may still use the old workspaces
 #undef C4_TRY
     (void)hipFree(b->d_y); (void)hipFree(b->d_z); (void)hipFree(b->d_phases); (void)hipFree(b->d_ss);
     (void)hipFree(b->d_sym_x); (void)hipFree(b->d_sym_idx); (void)hipFree(b->d_sym_sp);

@@ -202,6 +202,7 @@ __global__ __launch_bounds__(128) void k_cq_seq(CqArgs a) {
     const double2 sb0 = sp->buf[0], sb1 = sp->buf[1], sb2 = sp->buf[2], sb3 = sp->buf[3];
     const double2 *full = a.full + (size_t)c * (a.n_max + a.L - 1);
     double2 *sym = a.symbols ? a.symbols + (size_t)c * a.cap : a.symws + (size_t)c * a.symcap;
+    const size_t sym_lim = a.symbols ? a.cap : (a.cap < a.symcap ? a.cap : a.symcap);   // the buffer the symbols go to
     const double inv_sps = 1.0 / a.sps;
     const double R2 = 0.70710678118654746;   // 1 / 1.4142135623730951 as the reference computes it (kr / inv)
     // the 4-entry circular buffer of the timing loop, oldest first
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(128) void k_cq_seq(CqArgs a) {
                 s.prev_sym = make_double2(sr, si);
                 s.prev_dec = make_double2(dr, di);
                 // (the differential decode of the symbol -- an atan2 and a rounding, no feedback -- is k_cq_decode's)
-                if ((size_t)count < a.cap) {
+                if ((size_t)count < sym_lim) {
                     if (lane == 0) sym[count] = make_double2(sr, si);
                     count++;
                 }
@@ -551,7 +552,8 @@ extern "C" int wh_cqpsk_bank_reserve(wh_cqpsk_bank *b, size_t n_max, void *strea
     const size_t symcap = mm_symbol_bound(n_max, b->sps);
     WH_HIP(hipMalloc(&full, (size_t)b->C * (n_max + b->L - 1) * sizeof(double2)));
     hipError_t e = hipMalloc(&symws, (size_t)b->C * symcap * sizeof(double2));
-    if (e == hipSuccess) e = hipStreamSynchronize(as_stream(stream));   // earlier calls may still read the old workspaces
+    (void)stream;
+    if (e == hipSuccess) e = hipDeviceSynchronize();   // earlier calls (on whichever stream) may still read the old workspaces
     if (e != hipSuccess) { (void)hipFree(full); (void)hipFree(symws); return set_err(WH_E_HIP, "wh_cqpsk_bank_reserve: %s", hipGetErrorString(e)); }
     (void)hipFree(b->d_full);
     (void)hipFree(b->d_symws);
