@@ -707,6 +707,13 @@ def gen_cqpsk_big():
                                         d._timing_recovery._integrator])
         print(f"  cqpsk_big case {ci}: dibits={sum(len(x) for x in dib)}")
     out["n_cases"] = np.array(len(cases))
+    # a muted stretch (exact zeros): the rotated value of a zero sample is (+-0, +-0), its angle 0 or +-pi -> detector error 0
+    iq, _ = S.dqpsk_muted_iq()
+    d = RefCQPSK(sample_rate=48000, symbol_rate=12000)
+    parts = [d.demodulate(iq[:13000]), d.demodulate(iq[13000:])]
+    out["muted_sha"] = np.array(S.sha256(iq))
+    out["muted_dibits"] = np.concatenate(parts).astype(np.uint8)
+    out["muted_counts"] = np.array([len(x) for x in parts], dtype=np.int64)
     # MuellerMullerTED standalone at sps 5 and 5.2083 on a Costas-corrected carrier, two calls each
     iq, _ = S.dqpsk_iq(6000, 60000, 1513, symbol_rate=12000, snr_db=22.0, freq_offset_hz=30.0)
     x = CostasLoop().process_block(iq.astype(np.complex128))

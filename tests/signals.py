@@ -235,6 +235,16 @@ def dqpsk_iq(n: int, fs: float, seed: int, symbol_rate: float = 12000.0, snr_db:
     return x.astype(np.complex64), dib
 
 
+def dqpsk_muted_iq(n: int = 24000, fs: float = 48000, seed: int = 1720):
+    """dqpsk_iq with EXACT zeros: a 400-sample muted stretch (longer than the 65-tap matched filter) and three isolated zero
+    samples."""
+    iq, dib = dqpsk_iq(n, fs, seed, symbol_rate=12000.0, snr_db=20.0, freq_offset_hz=80.0)
+    iq = iq.copy()
+    iq[6000:6400] = 0
+    iq[[10, 9000, 15001]] = 0
+    return iq, dib
+
+
 # --------------------------------------------------------------------------
 # spectrum frames for the channel classifier (N4)
 # --------------------------------------------------------------------------

@@ -110,3 +110,15 @@ def test_mueller_muller_oracle_odd_sps(golden):
         assert np.max(np.abs(np.concatenate([a[0], b[0]]) - g[f"mm_{tag}_sym"])) <= 1e-12
         assert np.array_equal(np.concatenate([a[1], b[1]]), g[f"mm_{tag}_dec"])
         assert np.max(np.abs(np.concatenate([a[2], b[2]]) - g[f"mm_{tag}_err"])) <= 1e-12
+
+
+def test_cqpsk_oracle_muted_stretch(golden):
+    """Exact zeros in the input (`cqpsk_big` muted case, from the reference): the C oracle's libm atan2 follows the same
+    signed-zero conventions as np.angle, dibits equal over two calls."""
+    g = golden("cqpsk_big")
+    iq, _ = S.dqpsk_muted_iq()
+    assert S.sha256(iq) == str(g["muted_sha"])
+    d = CQPSKDemodulatorRef(sample_rate=48000, symbol_rate=12000)
+    parts = [d.demodulate(iq[:13000]), d.demodulate(iq[13000:])]
+    assert [len(x) for x in parts] == [int(v) for v in g["muted_counts"]]
+    assert np.array_equal(np.concatenate(parts), g["muted_dibits"])

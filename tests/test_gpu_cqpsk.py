@@ -129,3 +129,27 @@ def test_cqpsk_big_call_and_odd_samples_per_symbol(golden):
         assert np.max(np.abs(np.concatenate([a[2], b[2]]) - g[f"mm_{tag}_err"])) <= 1e-9
     with pytest.raises(Exception):
         wavehip.MuellerMullerTED(1.5)      # sps < 2: refused at create (was an integer division by zero on the host)
+
+
+def test_cqpsk_muted_stretch_vs_oracle(golden):
+    """Exact zeros in the input (a muted stretch longer than the matched filter, isolated zero samples): the rotated value
+    of a zero sample is (+-0, +-0), its angle 0 or +-pi in the reference -- detector error 0 either way -- so the carrier
+    loop coasts through it; the phase recurrence of round 3 carries that case explicitly.  Dibits equal, symbols <= 1e-9
+    against the C oracle (libm atan2 with its signed-zero conventions), state carried into a second call."""
+    import wavehip
+    from oracle.cqpsk_c import CQPSKDemodulatorRef
+
+    fs, sr, n = 48000, 12000, 24000
+    iq, _ = S.dqpsk_muted_iq(n, fs)
+    g = golden("cqpsk_big")
+    assert S.sha256(iq) == str(g["muted_sha"])
+    d, r = wavehip.CQPSKBank(1, fs, sr), CQPSKDemodulatorRef(fs, sr)
+    got = []
+    for lo, hi in ((0, 13000), (13000, n)):
+        (gd, gs), = d.demodulate(iq[None, lo:hi], want_symbols=True)
+        rd, rs = r.demodulate(iq[lo:hi], want_symbols=True)
+        assert np.array_equal(gd, rd), (lo, np.flatnonzero(gd[:len(rd)] != rd[:len(gd)])[:5])
+        assert np.max(np.abs(gs - rs)) <= 1e-9 * max(1.0, np.max(np.abs(rs)))
+        got.append(gd)
+    # ... and the reference itself
+    assert [len(x) for x in got] == [int(v) for v in g["muted_counts"]] and np.array_equal(np.concatenate(got), g["muted_dibits"])

@@ -174,7 +174,9 @@ __device__ __forceinline__ double cq_costas_block(CqCostas &c, double theta, int
                                            __builtin_amdgcn_readlane(__double2loint(theta), j));
         myphi = lane == j ? c.phase : myphi;
         const double d = DS(th, c.phase);
-        const double err = DS(d, DM(rint(DM(d, inv_q)), q));
+        // (an exactly-zero sample arrives as NaN: its rotated value is (+-0, +-0), whose angle is 0 or +-pi in the reference
+        // -- a multiple of pi / 4 either way, so the detector error is 0 and the loop coasts)
+        const double err = th != th ? 0.0 : DS(d, DM(rint(DM(d, inv_q)), q));
         c.freq = fmin(fmax(DA(c.freq, DM(ki, err)), -maxf), maxf);
         double ph = DA(c.phase, DA(DM(kp, err), c.freq));
         // the reference's `while phase > pi: phase -= 2 pi` loops as selects: |phase| <= pi before the step and the step is
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(128) void k_cq_seq(CqArgs a) {
             const int t0 = blk * 64;
             const double2 xl = t0 + lane < a.n ? full[t0 + lane] : make_double2(0.0, 0.0);
             const int m = a.n - t0 < 64 ? a.n - t0 : 64;
-            const double theta = cq_atan2(xl.y, xl.x);
+            const double theta = (xl.x == 0.0 && xl.y == 0.0) ? __longlong_as_double(0x7ff8000000000000LL) : cq_atan2(xl.y, xl.x);
             const double phi = cq_costas_block(cl, theta, m, lane, a.c_kp, a.c_ki, a.c_maxf);
             double sn, cs;
             cq_sincos(phi, sn, cs);
@@ -368,7 +370,8 @@ __global__ __launch_bounds__(64) void k_costas(const double2 *x, size_t stride, 
     for (int t0 = 0; t0 < n; t0 += 64) {
         const double2 xl = t0 + lane < n ? xc[t0 + lane] : make_double2(0.0, 0.0);
         const int m = n - t0 < 64 ? n - t0 : 64;
-        const double phi = cq_costas_block(cl, cq_atan2(xl.y, xl.x), m, lane, kp, ki, maxf);   // (see k_cq_seq)
+        const double th = (xl.x == 0.0 && xl.y == 0.0) ? __longlong_as_double(0x7ff8000000000000LL) : cq_atan2(xl.y, xl.x);
+        const double phi = cq_costas_block(cl, th, m, lane, kp, ki, maxf);   // (see k_cq_seq)
         double sn, cs;
         cq_sincos(phi, sn, cs);
         if (t0 + lane < n)                                     // sample * exp(-j phi): one coalesced store per 64
