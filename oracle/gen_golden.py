@@ -677,6 +677,21 @@ def gen_c4fm_big():
         print(f"  c4fm_big case {ci}: syms={sum(counts)} syncs={d._sync_count} fine={d._fine_sync} "
               f"bp={d._buffer_pointer} pll={d._equalizer.pll:.4f} gain={d._equalizer.gain:.4f}")
     out["n_cases"] = np.array(len(cases))
+    # muted input (exact zeros through both FIRs): the discriminator's products are signed zeros, its phase 0 or pi by
+    # their signs (np.arctan2), 100 ms calls and one 72 000-sample call
+    iq, _ = S.c4fm_muted_iq()
+    for tag, calls in (("muted_a", [4800] * 20), ("muted_b", [72000, 24000])):
+        d = rc4.C4FMDemodulator(sample_rate=48000)
+        dib, soft, counts, pos = [], [], [], 0
+        for m in calls:
+            a, b = d.demodulate(iq[pos:pos + m])
+            pos += m
+            dib.append(a); soft.append(b); counts.append(len(a))
+        out[f"{tag}_calls"] = np.array(calls, dtype=np.int64)
+        out[f"{tag}_dibits"] = np.concatenate(dib).astype(np.uint8)
+        out[f"{tag}_soft"] = np.concatenate(soft).astype(np.float32)
+        out[f"{tag}_counts"] = np.array(counts, dtype=np.int32)
+    out["muted_sha"] = np.array(S.sha256(iq))
     save("c4fm_big", **out)
 
 

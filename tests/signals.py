@@ -183,6 +183,15 @@ def c4fm_iq(
     return (iq + noise).astype(np.complex64), dib
 
 
+def c4fm_muted_iq(n: int = 96000, fs: int = 48000, seed: int = 1300):
+    """c4fm_iq with EXACT zeros: 6 000 muted samples (far longer than the filters) and three isolated zero samples."""
+    iq, dib = c4fm_iq(n, fs, seed, snr_db=20.0, freq_offset_hz=100.0)
+    iq = iq.copy()
+    iq[30000:36000] = 0
+    iq[[7, 50000, 50001]] = 0
+    return iq, dib
+
+
 def p25_head_stream_iq(fs: int = 48000, seed: int = 1500, reps: int = 3, snr_db: float = 20.0,
                        freq_offset_hz: float = 150.0):
     """IQ of a C4FM carrier whose dibits are `reps` different frame-head streams (nid_stream: sync + BCH-coded NID with

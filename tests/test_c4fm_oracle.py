@@ -110,3 +110,24 @@ def test_c4fm_oracle_matches_reference_at_production_call_sizes(golden, atan_mod
         st, ref = d.state(), g[f"c{ci}_state"]
         assert st["sync_count"] == int(ref[0]) and st["fine_sync"] == bool(ref[1]) and st["buffer_pointer"] == int(ref[5])
         assert abs(st["pll"] - ref[2]) <= 1e-5 and abs(st["gain"] - ref[3]) <= 1e-6 and abs(st["sample_point"] - ref[4]) <= 1e-6
+
+
+@pytest.mark.parametrize("atan_mode", [0, 1])
+def test_c4fm_oracle_muted_input(golden, atan_mode):
+    """Exact zeros in the input (`c4fm_big` muted cases, from the reference): zeros pass both FIRs exactly, the
+    discriminator's conjugate product is made of signed zeros and np.arctan2 returns 0 or +-pi by their signs -- both atan2
+    flavours of the oracle follow IEEE there (the portable one took the quadrant from `x < 0` until round 3 and returned 0
+    for (+0, -0): one dibit of 9 600 off on this stream)."""
+    g = golden("c4fm_big")
+    iq, _ = S.c4fm_muted_iq()
+    assert S.sha256(iq) == str(g["muted_sha"])
+    for tag in ("muted_a", "muted_b"):
+        d = C4FMDemodulatorRef(sample_rate=48000, atan_mode=atan_mode)
+        dib, soft, counts, pos = [], [], [], 0
+        for m in (int(v) for v in g[f"{tag}_calls"]):
+            a, b = d.demodulate(iq[pos:pos + m])
+            pos += m
+            dib.append(a); soft.append(b); counts.append(len(a))
+        assert np.array_equal(np.array(counts, dtype=np.int32), g[f"{tag}_counts"]), tag
+        assert np.array_equal(np.concatenate(dib), g[f"{tag}_dibits"]), tag
+        assert peak_rel_err(np.concatenate(soft), g[f"{tag}_soft"]) <= 1e-5, tag

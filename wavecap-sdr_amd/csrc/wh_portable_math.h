@@ -38,7 +38,9 @@
 #endif
 
 // atan2f, max error ~2 ulp.  Octant reduction + cephes atanf minimax polynomial.
-// Finite inputs only matter on this path; (0,0) -> 0 like C atan2f(+0,+0).
+// Signed zeros follow C / IEEE atan2f (and numpy's arctan2): the quadrant is taken from the SIGN BITS, so
+// atan2f(+-0, -0) = +-pi, atan2f(+-0, +0) = +-0, atan2f(-0, x < 0) = -pi -- a muted input (exact zeros through the filters)
+// reaches the C4FM discriminator as products of signed zeros, and the reference's phase there is 0 or pi by their signs.
 WHM_FN float whm_atan2f(float y, float x) {
     const float PI_F = 3.14159265358979323846f;
     const float PIO2_F = 1.57079632679489661923f;
@@ -66,8 +68,8 @@ WHM_FN float whm_atan2f(float y, float x) {
         r = WHM_ADD(base, p);
         if (ay > ax) r = WHM_SUB(PIO2_F, r);
     }
-    if (x < 0.0f) r = WHM_SUB(PI_F, r);
-    return y < 0.0f ? -r : r;
+    if (__builtin_signbit(x)) r = WHM_SUB(PI_F, r);
+    return __builtin_signbit(y) ? -r : r;
 }
 
 // sin/cos of a float32 phase given in radians, |phase| up to ~1e7: float64 range
