@@ -653,6 +653,26 @@ def test_chain_fm_exact_zero_samples(wh, O, golden):
     assert peak_rel_err(a, g["wbfm_audio"]) <= TOL and db_close([m["rssi_db"], m["signal_power_db"]], g["wbfm_met"])
 
 
+def test_chain_nbfm_extreme_offsets_vs_oracle(wh, O):
+    """The fused NBFM front adds the mixer's float32 phase step to the raw discriminator angle and wraps: offsets next to
+    +-fs / 2 (step ~ -+pi: every sample wraps), 1 Hz (step ~ 2.6e-6 rad), a non-integer offset (the reference rounds it,
+    capture.py:173) and 0.4 Hz (rounds to 0 Hz but still takes the mixed branch: offset_hz != 0.0)."""
+    fs, n = 2_400_000, 120_000
+    i16 = S.pack_iq16_np(S.nbfm_bank_c64(n, fs, seed=88))
+    z = i16.astype(np.float32) / 32768.0
+    z = (z[0::2] + 1j * z[1::2]).astype(np.complex64)
+    offs = [1_199_999.0, -1_199_990.0, 1.0, -37_500.6, 0.4, 600_000.0]
+    cfgs = [_nbfm_cfg(wh, o) for o in offs]
+    res = wh.ChannelBank(fs, n, cfgs, input_format="int16").process(i16)
+    for k, o in enumerate(offs):
+        a_ref, m_ref = O.process_channel_nbfm(z, fs, o)
+        a, m = res[k]
+        assert (a is None) == (a_ref is None), o
+        if a is not None:
+            assert peak_rel_err(a, a_ref) <= TOL, o
+        assert db_close(m["rssi_db"], m_ref["rssi_db"]), o
+
+
 def test_chain_spectral_noise_reduction(wh, golden):
     """enable_noise_reduction on the FM chains (dsp/filters.py:346-460): STFT / percentile floor / Wiener gain /
     ISTFT on the device; audio length follows the shortened row; < 1024-sample chunks pass through.
