@@ -50,13 +50,14 @@ def test_config3_pfb_full_size_2p28():
 
 
 def test_config3_int16_dma_prefetch_full_size_bit_equal():
-    """The int16 default of the 1024-channel kernel prefetches through the LDS DMA and waits with a COUNTED vmcnt (the
-    prefetch retires, the eight younger output stores stay in flight; MI355X_MICROARCH.md: loads, stores and LDS-DMA
-    count together, in issue order) into a double-buffered LDS target.  At 2^28 samples every workgroup walks 64 groups
-    with stores in flight and the whole chip contending for HBM -- the steady state the small tests never reach -- and
-    the whole 524 287 x 1024 output plus the carried history must equal the register-prefetch kernel on the unpacked
-    copy bit for bit; a second call runs with a no-arithmetic streaming kernel co-resident on another HIP stream to
-    perturb load / store timing."""
+    """The default form of the 1024-channel kernel (three workgroups per CU) prefetches through the LDS DMA and waits with
+    a COUNTED vmcnt (the prefetch retires, the sixteen younger output stores stay in flight; MI355X_MICROARCH.md: loads,
+    stores and LDS-DMA count together, in issue order) -- int16 input into a double-buffered LDS target, complex64 input
+    into a single buffer whose copy is issued after the group's first barrier.  At 2^28 samples the whole chip contends
+    for HBM with stores in flight -- the steady state the small tests never reach -- and the whole 524 287 x 1024 output
+    plus the carried history must equal the two-workgroup register-prefetch kernel on the unpacked copy bit for bit; a
+    second call runs with a no-arithmetic streaming kernel co-resident on another HIP stream to perturb load / store
+    timing; then the same for the default form on complex64 input (short and long runs) and the two-workgroup DMA form."""
     import torch
     import wavehip
     from wavehip import _lib
@@ -65,7 +66,7 @@ def test_config3_int16_dma_prefetch_full_size_bit_equal():
     g = torch.Generator(device="cuda").manual_seed(44)
     i16 = torch.randint(-12000, 12000, (2 * n,), dtype=torch.int16, device="cuda", generator=g)
     xq = torch.view_as_complex((i16.to(torch.float32) / 32768.0).view(n, 2))    # the A1 unpack rule, exact in float32
-    dma = wavehip.PolyphaseChannelizer(10_000_000, 9765)                          # int16 input: LDS-DMA form
+    dma = wavehip.PolyphaseChannelizer(10_000_000, 9765)                          # int16 input: the default form
     reg = wavehip.PolyphaseChannelizer(10_000_000, 9765).tune(prefetch=1)         # complex64 input, register prefetch
     ya = dma.process_device(i16)
     yb = reg.process_device(xq)
@@ -86,11 +87,13 @@ def test_config3_int16_dma_prefetch_full_size_bit_equal():
     torch.cuda.synchronize()
     assert torch.equal(ya, yb)
     assert np.array_equal(dma.arm_history, reg.arm_history)
-    # the DMA form on complex64 input as well (16 KB per group through the same double buffer)
-    ya = wavehip.PolyphaseChannelizer(10_000_000, 9765).tune(prefetch=3).process_device(xq, out=ya)
+    # the DMA forms on complex64 input as well: the default (single 16 KB buffer) at its own run length, at 12-hop and
+    # 256-hop runs, and the two-workgroup form (double buffer)
     reg.reset()
     yb = reg.process_device(xq, out=yb)
-    assert torch.equal(ya, yb)
+    for kw in (dict(), dict(hops_per_run=3, run_map=-1), dict(hops_per_run=64), dict(prefetch=3), dict(prefetch=7, hops_per_run=4)):
+        ya = wavehip.PolyphaseChannelizer(10_000_000, 9765).tune(**kw).process_device(xq, out=ya)
+        assert torch.equal(ya, yb), kw
 
 
 def test_config2_nbfm_10s_int16_bank():

@@ -1145,18 +1145,21 @@ def test_a7_pfb_other_tap_counts_vs_oracle(wh, O, fs, bw, M, T):
 
 
 def test_a7_pfb_prefetch_forms_agree(wh):
-    """The fused 1024-channel kernel prefetches the next group's samples either into registers (complex64 default) or
-    through the LDS DMA with counted waits (int16 default); tune(prefetch=1 / 3) forces one form for both formats.
-    Same arithmetic, so all four (format, form) pairs agree bit for bit, ragged tail and second call included."""
+    """The fused 1024-channel kernel prefetches the next group's samples either into registers or through the LDS DMA with
+    counted waits, at two or three workgroups per CU: tune(prefetch=1 / 3) are the two-workgroup forms, 7 / 5 the
+    three-workgroup forms (5 = the default, 0; different LDS images, 8-byte stores, a single DMA buffer for complex64),
+    and the run length / run -> workgroup mapping are free parameters.  Same arithmetic, so every (format, form, run
+    length, mapping) combination agrees bit for bit, ragged tail and second call included."""
     import torch
 
     x = S.noise_c64(1024 * 260 + 333, 77, amp=0.25)
     i16 = torch.from_numpy(S.pack_iq16_np(x)).cuda()
     xq = torch.from_numpy(wh.unpack_iq16(S.pack_iq16_np(x))).cuda()
     outs = {}
-    for v in ("1", "3"):
-        a = wh.PolyphaseChannelizer(10_000_000, 9765).tune(prefetch=int(v))
-        b = wh.PolyphaseChannelizer(10_000_000, 9765).tune(prefetch=int(v))
+    for v, kw in (("1", {}), ("3", {}), ("0", {}), ("5", dict(hops_per_run=3, run_map=-1)), ("5b", dict(hops_per_run=7, run_map=4)),
+                  ("5c", dict(hops_per_run=64, run_map=-2)), ("7", dict(hops_per_run=2)), ("7b", dict(hops_per_run=16, run_map=1))):
+        a = wh.PolyphaseChannelizer(10_000_000, 9765).tune(prefetch=int(v[0]), **kw)
+        b = wh.PolyphaseChannelizer(10_000_000, 9765).tune(prefetch=int(v[0]), **kw)
         cut = 1024 * 150 + 512
         outs[v] = [torch.cat([a.process_device(xq[:cut]), a.process_device(xq[cut:])]),
                    torch.cat([b.process_device(i16[:2 * cut]), b.process_device(i16[2 * cut:])])]

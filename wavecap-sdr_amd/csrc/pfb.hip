@@ -37,8 +37,8 @@ constexpr int FHOP = 512;
 constexpr int FT = 9;
 constexpr int GH = 4;          // hops per group (= waves per workgroup)
 constexpr int LDS1_K1 = 272;   // stage-1 image: idx = k1*272 + n2*16 + n3   (complex units)
-constexpr int LDS2_ROW = 18;   // stage-2 image: idx = (k2*4 + k1)*18 + n3
-constexpr int LDS_HOP = 1152;  // complex per hop image (max(4*272, 64*18))
+// stage-2 image: idx = (k2*4 + k1)*LDS2_ROW + n3, LDS2_ROW = 18 (17 in the three-workgroups-per-CU form); a hop image is
+// LDS_HOP = max(4*272, 64*LDS2_ROW) complex (both set in pfb1024_body)
 
 // input accessor: complex64 (FMT 0) or interleaved int16 IQ (FMT 1, A1 unpack rule int16/32768)
 template <int FMT>
@@ -62,6 +62,7 @@ struct PfbFastArgs {
     long long n_groups;     // total groups of GH hops
     int groups_per_wg;
     int n_wg;
+    int map_chunk;          // run -> workgroup mapping: -2 = one contiguous range of runs per XCD, -1 = run = workgroup, C > 0 = chunks of C
     long long max_block;    // last half-block (512 samples) fully inside the input: prefetches past it are clamped
     double *stats_ws;       // STATS: one row [4][1024] float64 per workgroup (sum p, sum p^2, min, max)
 #ifdef WH_DIAG
@@ -77,13 +78,22 @@ struct PfbFastArgs {
 // STATS: statistics-only mode (A13, the scanner's pass): stage 3 turns its 16 outputs per lane into float32 powers, the four
 // hops of a group meet in LDS (each wave's finished image is free by then) and thread t folds them into the accumulators
 // of its four channels t + 256 q; nothing is stored but one [4][1024] row per workgroup at the end.
-template <int FMT, bool GLDS = false, bool STATS = false>
-__global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
+// W3: the form held to THREE workgroups per CU (3 waves per SIMD, <= 168 VGPRs, <= 53 KB of LDS): the stage-2 image rows are
+// 17 complex apart instead of 18 (conflict-free for 8-byte reads: 34 l mod 64 is distinct over 32 lanes; stage 3 then reads
+// 16 x 8 bytes instead of 8 x 16), which makes a hop image 1088 complex = the stage-1 image's size; the complex64 DMA
+// target is a single buffer, its copy issued AFTER the group's first barrier (every wave has consumed the previous copy by
+// then: its LDS reads feed the arm MAC that precedes the barrier).
+template <int FMT, bool GLDS, bool STATS, bool W3>
+__device__ __forceinline__ void pfb1024_body(const PfbFastArgs &a) {
+    constexpr bool ST8 = W3;   // 8-byte stores without the lane exchange (see stage 3)
+    constexpr int LDS2_ROW = W3 ? 17 : 18;
+    constexpr int LDS_HOP = W3 ? 1088 : 1152;
     constexpr int PRE_BYTES = GLDS ? GH * FHOP * (FMT == 1 ? 4 : 8) : 0;   // GH half-blocks of samples
+    constexpr bool PRE_SINGLE = W3 && FMT == 0;
     // the DMA target is double-buffered: the copy for group g+2 is issued by whichever wave finishes group g+1's arm MAC
     // first, and lands while slower waves may still be reading group g+1's samples -- it must not share their buffer.
     // With two buffers a buffer is rewritten only after a workgroup barrier that follows its last reads.
-    __shared__ __attribute__((aligned(16))) float2 lds[GH * LDS_HOP + 256 + 2 * PRE_BYTES / 8];
+    __shared__ __attribute__((aligned(16))) float2 lds[GH * LDS_HOP + 256 + (PRE_SINGLE ? 1 : 2) * PRE_BYTES / 8];
     float2 *tw256 = lds + GH * LDS_HOP;
     unsigned char *pre0 = reinterpret_cast<unsigned char *>(lds + GH * LDS_HOP + 256);
 
@@ -93,10 +103,21 @@ __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
 
     // XCD-aware run mapping: blocks b and b+8 share an XCD (round-robin dispatch); give each
     // XCD a contiguous range of runs so that the 9-block halo of neighbouring runs hits its L2.
+    // map_chunk C > 0: chunks of C consecutive runs stay on one XCD, the chunks go round the XCDs -- the halo of C - 1 of C
+    // runs is an L2 hit AND the resident workgroups of the whole chip sweep ONE band of addresses (short runs: the band is
+    // what the HBM channels see); the grid is padded to a multiple of 8 C, the workgroups past the last run leave at once.
     int b = blockIdx.x;
     int nwg = a.n_wg;
     int per = nwg >> 3;
-    int run = (nwg & 7) == 0 ? (b & 7) * per + (b >> 3) : b;
+    int run;
+    if (a.map_chunk > 0) {
+        const int i = b >> 3, ch = i / a.map_chunk;
+        run = (ch * 8 + (b & 7)) * a.map_chunk + (i - ch * a.map_chunk);
+    } else if (a.map_chunk == -2) {
+        run = (nwg & 7) == 0 ? (b & 7) * per + (b >> 3) : b;
+    } else {
+        run = b;
+    }
 
     long long g0 = (long long)run * a.groups_per_wg;
     long long g1 = g0 + a.groups_per_wg;
@@ -109,30 +130,15 @@ __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
         return;
     }
 
-    // taps: arms[k][j] for k = t, t+256, t+512, t+768, kept as 18 register PAIRS (tap e = q * 9 + j is half e & 1 of pair
-    // e / 2): the arm MAC below is packed -- (re, im) * tap as one v_pk_fma_f32 with the tap broadcast from its half of the
-    // pair through op_sel -- half the instructions of the scalar form
-    typedef float v2f __attribute__((ext_vector_type(2)));
-    v2f tpr[(4 * FT) / 2];
-#pragma unroll
-    for (int e = 0; e < 4 * FT; e += 2) {
-        const int q0 = e / FT, j0 = e - q0 * FT, q1 = (e + 1) / FT, j1 = (e + 1) - q1 * FT;
-        tpr[e / 2] = v2f{a.arms[(t + 256 * q0) * FT + j0], a.arms[(t + 256 * q1) * FT + j1]};
-    }
-
-    // stage-1 twiddles W1024^(t*k1), k1 = 1..3
-    float2 tw1 = a.tw1024[t], tw2 = a.tw1024[(2 * t) & 1023], tw3 = a.tw1024[(3 * t) & 1023];
+    // Set-up: EVERY load of the prologue is issued before the first wait (a run is as short as 12 hops, so a workgroup's
+    // set-up latency is a visible share of its life: twiddles, window and taps used to be three round trips one after another --
+    // the table's barrier stood between the tap loads and the window fill).
     // stage-2 twiddles W256^(n3*k2) are read from a 2 KB LDS table laid out [k2][n3], so a wave's
     // read for one k2 is 16 consecutive entries (conflict-free, broadcast over k1, immediate offsets).
     // (Keeping the 15 per-lane values in registers pushes the kernel to 256 VGPRs: 18 % slower.)
-    tw256[t] = a.tw1024[(4 * (t & 15) * (t >> 4)) & 1023];
-    __syncthreads();
-
-    StAcc sacc[STATS ? 4 : 1];
-    if (STATS) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) stacc_init(sacc[q]);
-    }
+    const float2 tw256_t = a.tw1024[(4 * (t & 15) * (t >> 4)) & 1023];
+    // stage-1 twiddles W1024^(t*k1), k1 = 1..3
+    float2 tw1 = a.tw1024[t], tw2 = a.tw1024[(2 * t) & 1023], tw3 = a.tw1024[(3 * t) & 1023];
     long long h = a.first_hop + g0 * GH;  // first hop of this run
     // windows: wA[i] = x[(h-8+i)*512 + t], wB[i] = x[(h-8+i)*512 + t + 256], i = 0..8 carried,
     // i = 9..12 filled per group
@@ -145,11 +151,47 @@ __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
         wA[i] = ld_iq<FMT>(a.x, xp + i * FHOP);
         wB[i] = ld_iq<FMT>(a.x, xp + i * FHOP + 256);
     }
+    // taps: arms[k][j] for k = t, t+256, t+512, t+768, kept as 18 register PAIRS (tap e = q * 9 + j is half e & 1 of pair
+    // e / 2): the arm MAC below is packed -- (re, im) * tap as one v_pk_fma_f32 with the tap broadcast from its half of the
+    // pair through op_sel -- half the instructions of the scalar form
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f tpr[(4 * FT) / 2];
+#pragma unroll
+    for (int e = 0; e < 4 * FT; e += 2) {
+        const int q0 = e / FT, j0 = e - q0 * FT, q1 = (e + 1) / FT, j1 = (e + 1) - q1 * FT;
+        tpr[e / 2] = v2f{a.arms[(t + 256 * q0) * FT + j0], a.arms[(t + 256 * q1) * FT + j1]};
+    }
+    tw256[t] = tw256_t;
+    __syncthreads();
 
+    StAcc sacc[STATS ? 4 : 1];
+    if (STATS) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) stacc_init(sacc[q]);
+    }
+
+    // GH half-blocks from block `blk` on, contiguous in memory, copied linearly by the LDS DMA: 16 bytes per lane, lane-linear
+    // in LDS
+    constexpr int NJ = GLDS ? PRE_BYTES / 16 / 256 : 0;
+    auto dma_copy = [&](unsigned char *dst, long long blk) {
+        const unsigned char *src = reinterpret_cast<const unsigned char *>(a.x) + (size_t)blk * FHOP * (FMT == 1 ? 4 : 8);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const unsigned char *gp = src + (size_t)(j * 256 + t) * 16;
+            unsigned base = (unsigned)(uintptr_t)dst + (unsigned)(j * 256 + wave * 64) * 16;
+            base = __builtin_amdgcn_readfirstlane(base);
+            unsigned save;
+            asm volatile("s_mov_b32 %0, m0\n\t"
+                         "s_mov_b32 m0, %1\n\t"
+                         "global_load_lds_dwordx4 %2, off\n\t"
+                         "s_mov_b32 m0, %0"
+                         : "=&s"(save) : "s"(base), "v"(gp) : "memory");
+        }
+    };
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the window fill is complete before the loop, so that no wait for it is
                                           // placed inside the loop (the static wait would drain the stores in every iteration)
     for (long long g = g0; g < g1; ++g, h += GH) {
-        unsigned char *pre = pre0 + (((g - g0) & 1) ? PRE_BYTES : 0);   // buffer of the copy issued in this iteration
+        unsigned char *pre = pre0 + ((!PRE_SINGLE && ((g - g0) & 1)) ? PRE_BYTES : 0);   // buffer of the copy issued in this iteration
         // ---- arm MAC + radix-4 stage for GH hops --------------------------------------------
         // (the pairs stay PAIRS: seen through, the compiler keeps a broadcast {t, t} copy of every tap -- 72 registers)
 #pragma unroll
@@ -186,25 +228,15 @@ __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
             wA[i] = wA[i + GH];
             wB[i] = wB[i + GH];
         }
+        // (a copy TWO groups ahead -- a whole iteration of lead, and the counted wait below then leaves the previous
+        // iteration's stores in flight as well -- measured no faster on int16 input, 1.104 / 1.113 against 1.095 / 1.113 ms at
+        // two run lengths in one process: neither the copy's latency nor the store acknowledgements are what the loop waits
+        // for; complex64 input has no room for the second buffer at three workgroups per CU)
+        auto issue_dma = [&]() {
+            if (g + 1 < g1) dma_copy(pre, h + GH + 1);
+        };
         if (GLDS) {
-            if (g + 1 < g1) {   // (a second prefetch stage, one more group ahead, measured 1 % slower)
-                // GH half-blocks, contiguous in memory, copied linearly: 16 bytes per lane, lane-linear in LDS
-                constexpr int NJ = PRE_BYTES / 16 / 256;
-                const unsigned char *src = reinterpret_cast<const unsigned char *>(a.x) +
-                                           (size_t)(h + GH + 1) * FHOP * (FMT == 1 ? 4 : 8);
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const unsigned char *gp = src + (size_t)(j * 256 + t) * 16;
-                    unsigned base = (unsigned)(uintptr_t)pre + (unsigned)(j * 256 + wave * 64) * 16;
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    unsigned save;
-                    asm volatile("s_mov_b32 %0, m0\n\t"
-                                 "s_mov_b32 m0, %1\n\t"
-                                 "global_load_lds_dwordx4 %2, off\n\t"
-                                 "s_mov_b32 m0, %0"
-                                 : "=&s"(save) : "s"(base), "v"(gp) : "memory");
-                }
-            }
+            if (!PRE_SINGLE) issue_dma();
         } else {
             // register prefetch, UNCONDITIONAL (the last group of a run loads clamped blocks nobody uses): with the loads
             // under `if (g + 1 < g1)` the two paths into the next iteration carry different numbers of operations in
@@ -220,6 +252,7 @@ __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
             }
         }
         __syncthreads();
+        if (GLDS && PRE_SINGLE) issue_dma();
         // ---- stage 2 (radix-16 over n2) : wave = hop, lane = (k1, n3) ------------------------
         {
             float2 *L = lds + wave * LDS_HOP;
@@ -251,7 +284,12 @@ __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
             // 16 ds_read2_b32 (real/imag de-interleaved), which at the 144-byte row stride is a 4-way
             // bank conflict (measured: SQ_LDS_BANK_CONFLICT > SQ_ACTIVE_INST_LDS).  b128 reads of the
             // padded rows are conflict-free.  The asm loads are waited for explicitly (lgkmcnt).
-            {
+            if (W3) {
+                // rows 17 complex apart: 8-byte reads, conflict-free (34 l mod 64 distinct over 32 lanes)
+                const float2 *src = L + lane * LDS2_ROW;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) v[j] = src[j];
+            } else {
                 typedef float f4 __attribute__((ext_vector_type(4)));
                 const unsigned addr = static_cast<unsigned>(reinterpret_cast<uintptr_t>(L + lane * LDS2_ROW));
                 f4 r0, r1, r2, r3, r4, r5, r6, r7;
@@ -283,6 +321,13 @@ __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
                 float *pwv = reinterpret_cast<float *>(L);
 #pragma unroll
                 for (int j = 0; j < 16; ++j) pwv[lane + 64 * j] = stat_power(v[j].x, v[j].y);
+            } else if (ST8) {
+                // 8-byte stores, no lane exchange: 16 store instructions of 512 contiguous bytes per wave.  At three
+                // workgroups per CU the exchange (48 selects + 16 ds_bpermute per group; as 32 v_cndmask_b32_dpp it measured
+                // the same) no longer pays for the wider stores: 1.2075 against 1.2175 ms (exchange) / 1.2213 (DPP form)
+                float2 *o = a.out + (h + wave) * FM + lane;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) o[64 * j] = v[j];
             } else {
                 // 16-byte stores (+2.3 % over 8-byte ones): lanes 2m / 2m+1 swap half of their outputs so that
                 // the even lane owns (X[2m + 64 j], X[2m+1 + 64 j]) for j < 8 and the odd lane the pair for j >= 8
@@ -324,6 +369,7 @@ __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
             else
 #endif
             if (STATS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no stores behind the prefetch in this mode
+            else if (ST8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         }
         __syncthreads();
@@ -355,6 +401,11 @@ __global__ __launch_bounds__(256, 2) void pfb1024_kernel(PfbFastArgs a) {
             row[3 * FM + c] = (double)sacc[q].mx;
         }
     }
+}
+
+template <int FMT, bool GLDS = false, bool STATS = false, bool W3 = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W3 ? 3 : 2))) void pfb1024_kernel(PfbFastArgs a) {
+    pfb1024_body<FMT, GLDS, STATS, W3>(a);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -884,6 +935,7 @@ struct wh_pfb {
     size_t stats_ws_rows = 0;
     int cu_count = 256;
     int gpw_override = 0;       // wh_pfb_tune(WH_PFB_TUNE_HOPS_PER_RUN)
+    int map_chunk = 0;          // wh_pfb_tune(WH_PFB_TUNE_RUN_MAP), M = 1024: see PfbFastArgs::map_chunk
     int ablate = 0;             // diagnostics build only (WH_PFB_ABLATE)
     int variant = 0;            // wh_pfb_tune(WH_PFB_TUNE_PREFETCH): 1 = register prefetch, 3 = LDS-DMA prefetch, for both formats
     int path = 0;               // wh_pfb_tune(WH_PFB_TUNE_PATH): 0 auto, 1 per-hop kernel only, 2 run kernel, 3 shaped kernel
@@ -966,7 +1018,7 @@ extern "C" int wh_pfb_tune(wh_pfb *p, int key, int value) {
         p->path = value;
         return WH_OK;
     case WH_PFB_TUNE_PREFETCH:
-        if (value != 0 && value != 1 && value != 3) return set_err(WH_E_ARG, "wh_pfb_tune: prefetch %d", value);
+        if (value != 0 && value != 1 && value != 3 && value != 5 && value != 7 ) return set_err(WH_E_ARG, "wh_pfb_tune: prefetch %d", value);
         p->variant = value;
         return WH_OK;
 #ifdef WH_DIAG
@@ -977,6 +1029,10 @@ extern "C" int wh_pfb_tune(wh_pfb *p, int key, int value) {
     case WH_PFB_TUNE_HOPS_PER_RUN:
         if (value < 0 || value > 4096) return set_err(WH_E_ARG, "wh_pfb_tune: hops per run %d", value);
         p->gpw_override = value;
+        return WH_OK;
+    case WH_PFB_TUNE_RUN_MAP:
+        if (value < -2 || value > 4096) return set_err(WH_E_ARG, "wh_pfb_tune: run map %d", value);
+        p->map_chunk = value;
         return WH_OK;
     }
     return set_err(WH_E_ARG, "wh_pfb_tune: unknown key %d", key);
@@ -1174,12 +1230,18 @@ static int pfb_run_fmt(wh_pfb *p, const void *d_iq, int fmt, size_t n, float *d_
             a.tw1024 = p->d_tw;
             a.first_hop = 8;
             a.n_groups = n_groups;
-            // runs of 256 hops (halo 3 %; 128 hops measured 2.5-4 % slower at 2^28 samples), but at least ~8 workgroups
-            // per CU when the input allows
-            int gpw = 64;
+            // Run length.  Three-workgroups form (default): runs of 20 hops -- the resident workgroups of the chip then sweep one
+            // narrow band of addresses, which is worth more at the HBM channels than the halo re-reads cost (9 blocks per
+            // run, served past the L2: 1.45 x the input fetched at 20 hops; measured best between 12 and 24 hops on every box,
+            // DESIGN 3.1).  Two-workgroups forms: runs of 256 hops (halo 3 %).  Either way at least two rounds of resident
+            // workgroups when the input allows.
+            const bool w3 = p->variant == 0 || p->variant == 5 || p->variant == 7;
+            // (int16 input reads half the bytes: the band matters less to it and the long runs measured as good or better)
+            const bool short_runs = w3 && fmt != 1;
+            int gpw = short_runs ? 5 : 64;
             long long nwg = (n_groups + gpw - 1) / gpw;
-            while (gpw > 2 && nwg < (long long)p->cu_count * 8) {
-                gpw >>= 1;
+            while (gpw > 2 && nwg < (long long)p->cu_count * (w3 ? 6 : 8)) {
+                gpw = short_runs ? gpw - 1 : gpw >> 1;
                 nwg = (n_groups + gpw - 1) / gpw;
             }
             if (p->gpw_override > 0) {
@@ -1188,6 +1250,10 @@ static int pfb_run_fmt(wh_pfb *p, const void *d_iq, int fmt, size_t n, float *d_
             }
             a.groups_per_wg = gpw;
             a.n_wg = (int)nwg;
+            // automatic mapping: short runs in chunks of 16 per XCD (one band of addresses for the whole chip), long runs as
+            // one contiguous range per XCD (what rounds 1-2 measured best at 128-256 hops)
+            a.map_chunk = p->map_chunk != 0 ? p->map_chunk : (gpw <= 16 ? 16 : -2);
+            if (a.map_chunk > 0) nwg = (nwg + 8LL * a.map_chunk - 1) / (8LL * a.map_chunk) * (8LL * a.map_chunk);
             a.max_block = (long long)(n / (size_t)FHOP) - 1;
 #ifdef WH_DIAG
             a.ablate = p->ablate;
@@ -1196,8 +1262,17 @@ static int pfb_run_fmt(wh_pfb *p, const void *d_iq, int fmt, size_t n, float *d_
             // prefetch path: int16 input through the LDS DMA (16 bytes per lane instead of 4: 1.30 -> 1.15 ms per 2^28
             // samples), complex64 input through registers (the DMA detour costs it 4 %); WH_PFB_VARIANT = 1 / 3 forces
             // the register / DMA form for both
-            const bool dma = p->variant == 3 || (p->variant != 1 && fmt == 1);
-            if (dma) {
+            const bool dma = p->variant == 3;
+            if (p->variant == 0 || p->variant == 5 || p->variant == 7) {
+                // default (round 3): the three-workgroups-per-CU form with the LDS-DMA prefetch, both input formats   // three workgroups per CU: 5 = LDS-DMA prefetch, 7 = register prefetch
+                if (p->variant != 7) {
+                    if (fmt == 1) hipLaunchKernelGGL((pfb1024_kernel<1, true, false, true>), dim3((unsigned)nwg), dim3(256), 0, st, a);
+                    else hipLaunchKernelGGL((pfb1024_kernel<0, true, false, true>), dim3((unsigned)nwg), dim3(256), 0, st, a);
+                } else {
+                    if (fmt == 1) hipLaunchKernelGGL((pfb1024_kernel<1, false, false, true>), dim3((unsigned)nwg), dim3(256), 0, st, a);
+                    else hipLaunchKernelGGL((pfb1024_kernel<0, false, false, true>), dim3((unsigned)nwg), dim3(256), 0, st, a);
+                }
+            } else if (dma) {
                 if (fmt == 1) hipLaunchKernelGGL((pfb1024_kernel<1, true>), dim3((unsigned)nwg), dim3(256), 0, st, a);
                 else hipLaunchKernelGGL((pfb1024_kernel<0, true>), dim3((unsigned)nwg), dim3(256), 0, st, a);
             } else if (fmt == 1)
@@ -1337,7 +1412,7 @@ extern "C" int wh_pfb_run_stats(wh_pfb *p, const void *d_iq, int input_format, s
                 nwg = (n_groups + gpw - 1) / gpw;
             }
             if (p->gpw_override > 0) { gpw = p->gpw_override; nwg = (n_groups + gpw - 1) / gpw; }
-            a.groups_per_wg = gpw; a.n_wg = (int)nwg;
+            a.groups_per_wg = gpw; a.n_wg = (int)nwg; a.map_chunk = -2;
             a.max_block = (long long)(n / (size_t)FHOP) - 1;
 #ifdef WH_DIAG
             a.ablate = 0;
