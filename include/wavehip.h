@@ -183,12 +183,14 @@ int wh_pfb_set_history(wh_pfb *p, const float *h_hist, void *stream);
  * 3 = kernel shaped at compile time for this channel count; PREFETCH (M = 1024): 0 = automatic, 1 = registers,
  * 3 = LDS DMA with counted waits, 5 / 7 = the same two at three workgroups per CU; HOPS_PER_RUN: 0 = automatic;
  * RUN_MAP (M = 1024): which run of hops a workgroup walks -- 0 = automatic, -1 = run index = workgroup index, -2 = one
- * contiguous range of runs per XCD, C > 0 = chunks of C consecutive runs per XCD, chunks round the XCDs.  Outputs do
- * not depend on any of these. */
+ * contiguous range of runs per XCD, C > 0 = chunks of C consecutive runs per XCD, chunks round the XCDs; ALT_DIR
+ * (M = 1024, default 1): odd runs are walked downwards, so that neighbouring runs meet at their common border at the same
+ * time (halo loads become L2 hits).  Outputs do not depend on any of these. */
 #define WH_PFB_TUNE_PATH 1
 #define WH_PFB_TUNE_PREFETCH 2
 #define WH_PFB_TUNE_HOPS_PER_RUN 3
 #define WH_PFB_TUNE_RUN_MAP 5
+#define WH_PFB_TUNE_ALT_DIR 6
 int wh_pfb_tune(wh_pfb *p, int key, int value);
 /* measurement aid (bench.py roofline): when enabled, run() brackets the main filterbank kernel
  * with HIP events on the caller's stream; kernel_ms() waits for and returns the duration of

@@ -91,7 +91,8 @@ def test_config3_int16_dma_prefetch_full_size_bit_equal():
     # 256-hop runs, and the two-workgroup form (double buffer)
     reg.reset()
     yb = reg.process_device(xq, out=yb)
-    for kw in (dict(), dict(hops_per_run=3, run_map=-1), dict(hops_per_run=64), dict(prefetch=3), dict(prefetch=7, hops_per_run=4)):
+    for kw in (dict(), dict(hops_per_run=3, run_map=-1), dict(hops_per_run=64), dict(hops_per_run=5, alt_dir=0), dict(prefetch=3),
+               dict(prefetch=7, hops_per_run=4)):
         ya = wavehip.PolyphaseChannelizer(10_000_000, 9765).tune(**kw).process_device(xq, out=ya)
         assert torch.equal(ya, yb), kw
 

@@ -1147,8 +1147,8 @@ def test_a7_pfb_other_tap_counts_vs_oracle(wh, O, fs, bw, M, T):
 def test_a7_pfb_prefetch_forms_agree(wh):
     """The fused 1024-channel kernel prefetches the next group's samples either into registers or through the LDS DMA with
     counted waits, at two or three workgroups per CU: tune(prefetch=1 / 3) are the two-workgroup forms, 7 / 5 the
-    three-workgroup forms (5 = the default, 0; different LDS images, 8-byte stores, a single DMA buffer for complex64),
-    and the run length / run -> workgroup mapping are free parameters.  Same arithmetic, so every (format, form, run
+    three-workgroup forms (5 = the default, 0; different LDS images, 8-byte stores, a single DMA buffer for complex64, odd
+    runs walked DOWNWARDS unless alt_dir=0), and the run length / run -> workgroup mapping are free parameters.  Same arithmetic, so every (format, form, run
     length, mapping) combination agrees bit for bit, ragged tail and second call included."""
     import torch
 
@@ -1157,7 +1157,8 @@ def test_a7_pfb_prefetch_forms_agree(wh):
     xq = torch.from_numpy(wh.unpack_iq16(S.pack_iq16_np(x))).cuda()
     outs = {}
     for v, kw in (("1", {}), ("3", {}), ("0", {}), ("5", dict(hops_per_run=3, run_map=-1)), ("5b", dict(hops_per_run=7, run_map=4)),
-                  ("5c", dict(hops_per_run=64, run_map=-2)), ("7", dict(hops_per_run=2)), ("7b", dict(hops_per_run=16, run_map=1))):
+                  ("5c", dict(hops_per_run=64, run_map=-2)), ("5d", dict(hops_per_run=5, alt_dir=0)), ("5e", dict(hops_per_run=2, run_map=2)),
+                  ("7", dict(hops_per_run=2)), ("7b", dict(hops_per_run=16, run_map=1)), ("7c", dict(hops_per_run=9, alt_dir=0))):
         a = wh.PolyphaseChannelizer(10_000_000, 9765).tune(prefetch=int(v[0]), **kw)
         b = wh.PolyphaseChannelizer(10_000_000, 9765).tune(prefetch=int(v[0]), **kw)
         cut = 1024 * 150 + 512

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Kernel-variant sweep for the fused filterbank (diagnostics; interleaved rounds in ONE process).
 usage: python tools/pfb_sweep.py "variant,gpw,ablate" ...   e.g.  1,16,0 1,32,0 1,32,1
-(variant = tune(prefetch=...): 0 automatic, 1 registers, 3 LDS DMA; gpw = run length in groups of 4 hops,
-tune(hops_per_run=gpw); ablate needs a library built with `make DIAG=1` and its WH_PFB_ABLATE=1 (no stores) -- the release
+(variant = tune(prefetch=...): 0 automatic, 1 registers, 3 LDS DMA, 5 / 7 the three-workgroups forms; gpw = run length in groups of 4 hops,
+tune(hops_per_run=gpw); ablate needs a library built with `make DIAG=1` and its WH_PFB_ABLATE bits: 1 = no stores, 2 = DMA copies from cache-resident blocks -- the release
 library has no such switch)"""
 import os, sys, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "wavecap-sdr_amd")]
+sys.path[:0] = [ROOT, os.environ.get("WAVEHIP_PKG_DIR", os.path.join(ROOT, "wavecap-sdr_amd"))]   # WAVEHIP_PKG_DIR: a scratch (DIAG) build
 import torch
 import wavehip
 
@@ -16,7 +16,7 @@ cfgs = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or [(1, 16, 0
 chs = []
 for var, gpw, abl in cfgs:
     os.environ["WH_PFB_ABLATE"] = str(abl)       # read by a DIAG build only
-    ch = wavehip.PolyphaseChannelizer(10_000_000, 9765).tune(prefetch=var if var in (1, 3) else 0, hops_per_run=gpw)
+    ch = wavehip.PolyphaseChannelizer(10_000_000, 9765).tune(prefetch=var, hops_per_run=gpw)
     ch.profile(True)
     chs.append(ch)
 out = torch.empty((chs[0].hops(n), 1024), dtype=torch.complex64, device="cuda")

@@ -4,7 +4,7 @@ three-workgroups-per-CU forms (5 = LDS-DMA, 7 = registers) -- same outputs? kern
 one process, complex64 and int16 input, at several run lengths (groups of 4 hops per workgroup; 0 = built-in).  Diagnostics."""
 import os, sys, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "wavecap-sdr_amd")]
+sys.path[:0] = [ROOT, os.environ.get("WAVEHIP_PKG_DIR", os.path.join(ROOT, "wavecap-sdr_amd"))]   # WAVEHIP_PKG_DIR: a scratch (DIAG) build
 import torch, wavehip
 n = 1 << int(os.environ.get("LOG2N", "28"))
 variants = [int(v) for v in os.environ.get("VARIANTS", "1,3,5,7").split(",")]

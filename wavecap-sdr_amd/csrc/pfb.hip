@@ -62,6 +62,7 @@ struct PfbFastArgs {
     long long n_groups;     // total groups of GH hops
     int groups_per_wg;
     int n_wg;
+    int alt_dir;            // odd runs walk downwards (three-workgroups form; see pfb1024_body)
     int map_chunk;          // run -> workgroup mapping: -2 = one contiguous range of runs per XCD, -1 = run = workgroup, C > 0 = chunks of C
     long long max_block;    // last half-block (512 samples) fully inside the input: prefetches past it are clamped
     double *stats_ws;       // STATS: one row [4][1024] float64 per workgroup (sum p, sum p^2, min, max)
@@ -83,52 +84,38 @@ struct PfbFastArgs {
 // 16 x 8 bytes instead of 8 x 16), which makes a hop image 1088 complex = the stage-1 image's size; the complex64 DMA
 // target is a single buffer, its copy issued AFTER the group's first barrier (every wave has consumed the previous copy by
 // then: its LDS reads feed the arm MAC that precedes the barrier).
+// DIR: the direction a workgroup walks its run of hops: +1 upwards (groups g0, g0 + 1, ...), -1 DOWNWARDS (g1 - 1, g1 - 2, ...:
+// the window slides the other way, the new blocks enter at its low end).  Odd runs walk downwards when the launch asks
+// for it (PfbFastArgs::alt_dir): run r - 1 (up) and run r (down) then both reach their common border at the END of their
+// walks, run r (down) and run r + 1 (up) both start at theirs -- the 8 halo blocks either neighbour needs from the other's
+// range are loaded by both at about the same time, so the second load is an L2 hit (same XCD: chunked mapping).  Walking
+// every run upwards the two loads are a whole run apart in time (all resident workgroups are in phase), further than the
+// 4 MB L2 reaches: the halo was fetched through the fabric a second time (FETCH_SIZE 1.45 x the input at 20-hop runs).
 template <int FMT, bool GLDS, bool STATS, bool W3>
-__device__ __forceinline__ void pfb1024_body(const PfbFastArgs &a) {
+struct Pfb1024Lds {
+    static constexpr int LDS_HOP = W3 ? 1088 : 1152;
+    static constexpr int PRE_BYTES = GLDS ? GH * FHOP * (FMT == 1 ? 4 : 8) : 0;   // GH half-blocks of samples
+    static constexpr bool PRE_SINGLE = W3 && FMT == 0;
+    static constexpr int WORDS = GH * LDS_HOP + 256 + (PRE_SINGLE ? 1 : 2) * PRE_BYTES / 8;   // float2 units
+};
+
+template <int FMT, bool GLDS, bool STATS, bool W3, int DIR>
+__device__ __forceinline__ void pfb1024_body(const PfbFastArgs &a, float2 *lds, long long g0, long long g1) {
     constexpr bool ST8 = W3;   // 8-byte stores without the lane exchange (see stage 3)
     constexpr int LDS2_ROW = W3 ? 17 : 18;
-    constexpr int LDS_HOP = W3 ? 1088 : 1152;
-    constexpr int PRE_BYTES = GLDS ? GH * FHOP * (FMT == 1 ? 4 : 8) : 0;   // GH half-blocks of samples
-    constexpr bool PRE_SINGLE = W3 && FMT == 0;
+    constexpr int LDS_HOP = Pfb1024Lds<FMT, GLDS, STATS, W3>::LDS_HOP;
+    constexpr int PRE_BYTES = Pfb1024Lds<FMT, GLDS, STATS, W3>::PRE_BYTES;
+    constexpr bool PRE_SINGLE = Pfb1024Lds<FMT, GLDS, STATS, W3>::PRE_SINGLE;
     // the DMA target is double-buffered: the copy for group g+2 is issued by whichever wave finishes group g+1's arm MAC
     // first, and lands while slower waves may still be reading group g+1's samples -- it must not share their buffer.
     // With two buffers a buffer is rewritten only after a workgroup barrier that follows its last reads.
-    __shared__ __attribute__((aligned(16))) float2 lds[GH * LDS_HOP + 256 + (PRE_SINGLE ? 1 : 2) * PRE_BYTES / 8];
     float2 *tw256 = lds + GH * LDS_HOP;
     unsigned char *pre0 = reinterpret_cast<unsigned char *>(lds + GH * LDS_HOP + 256);
+    constexpr int NEW0 = DIR > 0 ? 9 : 0;   // window slots the next group's new blocks enter
 
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = t >> 6;
-
-    // XCD-aware run mapping: blocks b and b+8 share an XCD (round-robin dispatch); give each
-    // XCD a contiguous range of runs so that the 9-block halo of neighbouring runs hits its L2.
-    // map_chunk C > 0: chunks of C consecutive runs stay on one XCD, the chunks go round the XCDs -- the halo of C - 1 of C
-    // runs is an L2 hit AND the resident workgroups of the whole chip sweep ONE band of addresses (short runs: the band is
-    // what the HBM channels see); the grid is padded to a multiple of 8 C, the workgroups past the last run leave at once.
-    int b = blockIdx.x;
-    int nwg = a.n_wg;
-    int per = nwg >> 3;
-    int run;
-    if (a.map_chunk > 0) {
-        const int i = b >> 3, ch = i / a.map_chunk;
-        run = (ch * 8 + (b & 7)) * a.map_chunk + (i - ch * a.map_chunk);
-    } else if (a.map_chunk == -2) {
-        run = (nwg & 7) == 0 ? (b & 7) * per + (b >> 3) : b;
-    } else {
-        run = b;
-    }
-
-    long long g0 = (long long)run * a.groups_per_wg;
-    long long g1 = g0 + a.groups_per_wg;
-    if (g1 > a.n_groups) g1 = a.n_groups;
-    if (g0 >= g1) {
-        if (STATS) {   // (never the case with the launcher's grid; an empty row all the same)
-            double *row = a.stats_ws + (size_t)blockIdx.x * 4 * FM;
-            for (int c = threadIdx.x; c < FM; c += 256) { row[c] = 0.0; row[FM + c] = 0.0; row[2 * FM + c] = INFINITY; row[3 * FM + c] = 0.0; }
-        }
-        return;
-    }
 
     // Set-up: EVERY load of the prologue is issued before the first wait (a run is as short as 12 hops, so a workgroup's
     // set-up latency is a visible share of its life: twiddles, window and taps used to be three round trips one after another --
@@ -139,7 +126,7 @@ __device__ __forceinline__ void pfb1024_body(const PfbFastArgs &a) {
     const float2 tw256_t = a.tw1024[(4 * (t & 15) * (t >> 4)) & 1023];
     // stage-1 twiddles W1024^(t*k1), k1 = 1..3
     float2 tw1 = a.tw1024[t], tw2 = a.tw1024[(2 * t) & 1023], tw3 = a.tw1024[(3 * t) & 1023];
-    long long h = a.first_hop + g0 * GH;  // first hop of this run
+    long long h = a.first_hop + (DIR > 0 ? g0 : g1 - 1) * GH;  // first hop of the first group of the walk
     // windows: wA[i] = x[(h-8+i)*512 + t], wB[i] = x[(h-8+i)*512 + t + 256], i = 0..8 carried,
     // i = 9..12 filled per group
     // window slots 0..8 carry c_{h-8..h}; slots 9..12 double as the prefetch buffer of the
@@ -174,6 +161,9 @@ __device__ __forceinline__ void pfb1024_body(const PfbFastArgs &a) {
     // in LDS
     constexpr int NJ = GLDS ? PRE_BYTES / 16 / 256 : 0;
     auto dma_copy = [&](unsigned char *dst, long long blk) {
+#ifdef WH_DIAG
+        if (a.ablate & 2) blk = 9 + (blk & 15);   // diagnostics: every copy reads the same few (cache-resident) blocks
+#endif
         const unsigned char *src = reinterpret_cast<const unsigned char *>(a.x) + (size_t)blk * FHOP * (FMT == 1 ? 4 : 8);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -190,8 +180,10 @@ __device__ __forceinline__ void pfb1024_body(const PfbFastArgs &a) {
     };
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the window fill is complete before the loop, so that no wait for it is
                                           // placed inside the loop (the static wait would drain the stores in every iteration)
-    for (long long g = g0; g < g1; ++g, h += GH) {
-        unsigned char *pre = pre0 + ((!PRE_SINGLE && ((g - g0) & 1)) ? PRE_BYTES : 0);   // buffer of the copy issued in this iteration
+    const long long ng = g1 - g0;
+    for (long long it = 0; it < ng; ++it, h += DIR * GH) {
+        const bool more = it + 1 < ng;
+        unsigned char *pre = pre0 + ((!PRE_SINGLE && (it & 1)) ? PRE_BYTES : 0);   // buffer of the copy issued in this iteration
         // ---- arm MAC + radix-4 stage for GH hops --------------------------------------------
         // (the pairs stay PAIRS: seen through, the compiler keeps a broadcast {t, t} copy of every tap -- 72 registers)
 #pragma unroll
@@ -222,18 +214,27 @@ __device__ __forceinline__ void pfb1024_body(const PfbFastArgs &a) {
             L[2 * LDS1_K1 + t] = y2;
             L[3 * LDS1_K1 + t] = y3;
         }
-        // slide the windows, then issue the next group's loads into the freed tail slots
+        // slide the windows, then issue the next group's loads into the freed slots (the tail walking up, the head walking down)
+        if (DIR > 0) {
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            wA[i] = wA[i + GH];
-            wB[i] = wB[i + GH];
+            for (int i = 0; i < 9; ++i) {
+                wA[i] = wA[i + GH];
+                wB[i] = wB[i + GH];
+            }
+        } else {
+#pragma unroll
+            for (int i = 8; i >= 0; --i) {
+                wA[i + GH] = wA[i];
+                wB[i + GH] = wB[i];
+            }
         }
+        const long long nblk = DIR > 0 ? h + GH + 1 : h - GH - 8;   // first of the next group's GH new half-blocks
         // (a copy TWO groups ahead -- a whole iteration of lead, and the counted wait below then leaves the previous
         // iteration's stores in flight as well -- measured no faster on int16 input, 1.104 / 1.113 against 1.095 / 1.113 ms at
         // two run lengths in one process: neither the copy's latency nor the store acknowledgements are what the loop waits
         // for; complex64 input has no room for the second buffer at three workgroups per CU)
         auto issue_dma = [&]() {
-            if (g + 1 < g1) dma_copy(pre, h + GH + 1);
+            if (more) dma_copy(pre, nblk);
         };
         if (GLDS) {
             if (!PRE_SINGLE) issue_dma();
@@ -245,10 +246,10 @@ __device__ __forceinline__ void pfb1024_body(const PfbFastArgs &a) {
             // flight)
 #pragma unroll
             for (int i = 0; i < GH; ++i) {
-                long long blk = h + GH + 1 + i;
-                blk = blk > a.max_block ? a.max_block : blk;
-                wA[9 + i] = ld_iq<FMT>(a.x, blk * FHOP + t);
-                wB[9 + i] = ld_iq<FMT>(a.x, blk * FHOP + t + 256);
+                long long blk = nblk + i;
+                blk = blk > a.max_block ? a.max_block : (DIR < 0 && blk < 0 ? 0 : blk);
+                wA[NEW0 + i] = ld_iq<FMT>(a.x, blk * FHOP + t);
+                wB[NEW0 + i] = ld_iq<FMT>(a.x, blk * FHOP + t + 256);
             }
         }
         __syncthreads();
@@ -327,7 +328,11 @@ __device__ __forceinline__ void pfb1024_body(const PfbFastArgs &a) {
                 // the same) no longer pays for the wider stores: 1.2075 against 1.2175 ms (exchange) / 1.2213 (DPP form)
                 float2 *o = a.out + (h + wave) * FM + lane;
 #pragma unroll
-                for (int j = 0; j < 16; ++j) o[64 * j] = v[j];
+                for (int j = 0; j < 16; ++j)
+#ifdef WH_DIAG
+                    if (!(a.ablate & 1) || v[j].x == 1.2345e30f)
+#endif
+                    o[64 * j] = v[j];
             } else {
                 // 16-byte stores (+2.3 % over 8-byte ones): lanes 2m / 2m+1 swap half of their outputs so that
                 // the even lane owns (X[2m + 64 j], X[2m+1 + 64 j]) for j < 8 and the odd lane the pair for j >= 8
@@ -342,7 +347,7 @@ __device__ __forceinline__ void pfb1024_body(const PfbFastArgs &a) {
                     float2 lo = even ? v[j] : rcv;
                     float2 hi = even ? rcv : v[j + 8];
 #ifdef WH_DIAG
-                    if (a.ablate != 1 || lo.x == 1.2345e30f)
+                    if (!(a.ablate & 1) || lo.x == 1.2345e30f)
 #endif
                     o4[32 * j] = make_float4(lo.x, lo.y, hi.x, hi.y);
                 }
@@ -355,7 +360,7 @@ __device__ __forceinline__ void pfb1024_body(const PfbFastArgs &a) {
 #pragma unroll
                 for (int w = 0; w < GH; ++w)      // the group's hops in order
                     stacc_add(sacc[q], reinterpret_cast<const float *>(lds + w * LDS_HOP)[t + 256 * q]);
-            if (((g - g0 + 1) & 3) == 0) {        // open float32 blocks are folded after 16 hops
+            if (((it + 1) & 3) == 0) {            // open float32 blocks are folded after 16 hops
 #pragma unroll
                 for (int q = 0; q < 4; ++q) stacc_fold(sacc[q]);
             }
@@ -373,18 +378,18 @@ __device__ __forceinline__ void pfb1024_body(const PfbFastArgs &a) {
             else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         }
         __syncthreads();
-        if (GLDS && g + 1 < g1) {
+        if (GLDS && more) {
 #pragma unroll
             for (int i = 0; i < GH; ++i) {
                 if (FMT == 1) {
                     const short2 *p16 = reinterpret_cast<const short2 *>(pre);
                     const short2 va = p16[i * FHOP + t], vb = p16[i * FHOP + t + 256];
-                    wA[9 + i] = make_float2((float)va.x * (1.0f / 32768.0f), (float)va.y * (1.0f / 32768.0f));
-                    wB[9 + i] = make_float2((float)vb.x * (1.0f / 32768.0f), (float)vb.y * (1.0f / 32768.0f));
+                    wA[NEW0 + i] = make_float2((float)va.x * (1.0f / 32768.0f), (float)va.y * (1.0f / 32768.0f));
+                    wB[NEW0 + i] = make_float2((float)vb.x * (1.0f / 32768.0f), (float)vb.y * (1.0f / 32768.0f));
                 } else {
                     const float2 *p32 = reinterpret_cast<const float2 *>(pre);
-                    wA[9 + i] = p32[i * FHOP + t];
-                    wB[9 + i] = p32[i * FHOP + t + 256];
+                    wA[NEW0 + i] = p32[i * FHOP + t];
+                    wB[NEW0 + i] = p32[i * FHOP + t + 256];
                 }
             }
         }
@@ -405,7 +410,38 @@ __device__ __forceinline__ void pfb1024_body(const PfbFastArgs &a) {
 
 template <int FMT, bool GLDS = false, bool STATS = false, bool W3 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W3 ? 3 : 2))) void pfb1024_kernel(PfbFastArgs a) {
-    pfb1024_body<FMT, GLDS, STATS, W3>(a);
+    __shared__ __attribute__((aligned(16))) float2 lds[Pfb1024Lds<FMT, GLDS, STATS, W3>::WORDS];
+    // XCD-aware run mapping: blocks b and b+8 share an XCD (round-robin dispatch); give each
+    // XCD a contiguous range of runs so that the 9-block halo of neighbouring runs hits its L2.
+    // map_chunk C > 0: chunks of C consecutive runs stay on one XCD, the chunks go round the XCDs -- the halo of C - 1 of C
+    // runs is an L2 hit AND the resident workgroups of the whole chip sweep ONE band of addresses (short runs: the band is
+    // what the HBM channels see); the grid is padded to a multiple of 8 C, the workgroups past the last run leave at once.
+    int b = blockIdx.x;
+    int nwg = a.n_wg;
+    int per = nwg >> 3;
+    int run;
+    if (a.map_chunk > 0) {
+        const int i = b >> 3, ch = i / a.map_chunk;
+        run = (ch * 8 + (b & 7)) * a.map_chunk + (i - ch * a.map_chunk);
+    } else if (a.map_chunk == -2) {
+        run = (nwg & 7) == 0 ? (b & 7) * per + (b >> 3) : b;
+    } else {
+        run = b;
+    }
+
+    long long g0 = (long long)run * a.groups_per_wg;
+    long long g1 = g0 + a.groups_per_wg;
+    if (g1 > a.n_groups) g1 = a.n_groups;
+    if (g0 >= g1) {
+        if (STATS) {   // (never the case with the launcher's grid; an empty row all the same)
+            double *row = a.stats_ws + (size_t)blockIdx.x * 4 * FM;
+            for (int c = threadIdx.x; c < FM; c += 256) { row[c] = 0.0; row[FM + c] = 0.0; row[2 * FM + c] = INFINITY; row[3 * FM + c] = 0.0; }
+        }
+        return;
+    }
+
+    if (W3 && !STATS && a.alt_dir && (run & 1)) pfb1024_body<FMT, GLDS, STATS, W3, -1>(a, lds, g0, g1);
+    else pfb1024_body<FMT, GLDS, STATS, W3, 1>(a, lds, g0, g1);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -936,6 +972,7 @@ struct wh_pfb {
     int cu_count = 256;
     int gpw_override = 0;       // wh_pfb_tune(WH_PFB_TUNE_HOPS_PER_RUN)
     int map_chunk = 0;          // wh_pfb_tune(WH_PFB_TUNE_RUN_MAP), M = 1024: see PfbFastArgs::map_chunk
+    int alt_dir = 1;            // wh_pfb_tune(WH_PFB_TUNE_ALT_DIR), M = 1024: odd runs walk downwards
     int ablate = 0;             // diagnostics build only (WH_PFB_ABLATE)
     int variant = 0;            // wh_pfb_tune(WH_PFB_TUNE_PREFETCH): 1 = register prefetch, 3 = LDS-DMA prefetch, for both formats
     int path = 0;               // wh_pfb_tune(WH_PFB_TUNE_PATH): 0 auto, 1 per-hop kernel only, 2 run kernel, 3 shaped kernel
@@ -1033,6 +1070,10 @@ extern "C" int wh_pfb_tune(wh_pfb *p, int key, int value) {
     case WH_PFB_TUNE_RUN_MAP:
         if (value < -2 || value > 4096) return set_err(WH_E_ARG, "wh_pfb_tune: run map %d", value);
         p->map_chunk = value;
+        return WH_OK;
+    case WH_PFB_TUNE_ALT_DIR:
+        if (value != 0 && value != 1) return set_err(WH_E_ARG, "wh_pfb_tune: alt dir %d", value);
+        p->alt_dir = value;
         return WH_OK;
     }
     return set_err(WH_E_ARG, "wh_pfb_tune: unknown key %d", key);
@@ -1230,18 +1271,16 @@ static int pfb_run_fmt(wh_pfb *p, const void *d_iq, int fmt, size_t n, float *d_
             a.tw1024 = p->d_tw;
             a.first_hop = 8;
             a.n_groups = n_groups;
-            // Run length.  Three-workgroups form (default): runs of 20 hops -- the resident workgroups of the chip then sweep one
-            // narrow band of addresses, which is worth more at the HBM channels than the halo re-reads cost (9 blocks per
-            // run, served past the L2: 1.45 x the input fetched at 20 hops; measured best between 12 and 24 hops on every box,
-            // DESIGN 3.1).  Two-workgroups forms: runs of 256 hops (halo 3 %).  Either way at least two rounds of resident
-            // workgroups when the input allows.
+            // Run length.  Three-workgroups form (default): runs of 32 hops (48 for int16 input), neighbouring runs walked in
+            // opposite directions -- the resident workgroups of the chip then sweep one narrow band of addresses, which the
+            // HBM channels serve better than 768 scattered streams, and the 9-block halo of a run is an L2 hit (FETCH_SIZE
+            // 1.08 x the input at 32 hops; 1.28 x when every run walks upwards).  Two-workgroups forms: runs of
+            // 256 hops (halo 3 %).  Either way at least two rounds of resident workgroups when the input allows.
             const bool w3 = p->variant == 0 || p->variant == 5 || p->variant == 7;
-            // (int16 input reads half the bytes: the band matters less to it and the long runs measured as good or better)
-            const bool short_runs = w3 && fmt != 1;
-            int gpw = short_runs ? 5 : 64;
+            int gpw = w3 ? (fmt == 1 ? 12 : 8) : 64;
             long long nwg = (n_groups + gpw - 1) / gpw;
             while (gpw > 2 && nwg < (long long)p->cu_count * (w3 ? 6 : 8)) {
-                gpw = short_runs ? gpw - 1 : gpw >> 1;
+                gpw = w3 ? gpw - 1 : gpw >> 1;
                 nwg = (n_groups + gpw - 1) / gpw;
             }
             if (p->gpw_override > 0) {
@@ -1253,6 +1292,7 @@ static int pfb_run_fmt(wh_pfb *p, const void *d_iq, int fmt, size_t n, float *d_
             // automatic mapping: short runs in chunks of 16 per XCD (one band of addresses for the whole chip), long runs as
             // one contiguous range per XCD (what rounds 1-2 measured best at 128-256 hops)
             a.map_chunk = p->map_chunk != 0 ? p->map_chunk : (gpw <= 16 ? 16 : -2);
+            a.alt_dir = p->alt_dir;
             if (a.map_chunk > 0) nwg = (nwg + 8LL * a.map_chunk - 1) / (8LL * a.map_chunk) * (8LL * a.map_chunk);
             a.max_block = (long long)(n / (size_t)FHOP) - 1;
 #ifdef WH_DIAG
@@ -1412,7 +1452,7 @@ extern "C" int wh_pfb_run_stats(wh_pfb *p, const void *d_iq, int input_format, s
                 nwg = (n_groups + gpw - 1) / gpw;
             }
             if (p->gpw_override > 0) { gpw = p->gpw_override; nwg = (n_groups + gpw - 1) / gpw; }
-            a.groups_per_wg = gpw; a.n_wg = (int)nwg; a.map_chunk = -2;
+            a.groups_per_wg = gpw; a.n_wg = (int)nwg; a.map_chunk = -2; a.alt_dir = 0;
             a.max_block = (long long)(n / (size_t)FHOP) - 1;
 #ifdef WH_DIAG
             a.ablate = 0;

@@ -108,12 +108,12 @@ class PolyphaseChannelizer:
         d = torch.from_numpy(x).cuda()
         return self.process_device(d).cpu().numpy()
 
-    TUNE_KEYS = {"path": 1, "prefetch": 2, "hops_per_run": 3, "run_map": 5}
+    TUNE_KEYS = {"path": 1, "prefetch": 2, "hops_per_run": 3, "run_map": 5, "alt_dir": 6}
     PATHS = {"auto": 0, "per_hop": 1, "run": 2, "shaped": 3}
 
     def tune(self, **kw) -> "PolyphaseChannelizer":
         """Explicit kernel selection for tests / measurements (wh_pfb_tune): path="auto"|"per_hop"|"run"|"shaped",
-        prefetch=0|1|3|5|7 (5 / 7: the three-workgroups-per-CU forms), hops_per_run=int, run_map=0|-1|-2|C."""
+        prefetch=0|1|3|5|7 (5 / 7: the three-workgroups-per-CU forms), hops_per_run=int, run_map=0|-1|-2|C, alt_dir=0|1."""
         for k, v in kw.items():
             if k == "path" and isinstance(v, str):
                 v = self.PATHS[v]
@@ -133,7 +133,7 @@ class PolyphaseChannelizer:
 
         M1024 = self.channel_count == 1024 and self.taps_per_channel == 9
         if candidates is None:      # 1024 channels: groups of 4 hops per workgroup; shaped kernels: hops per run
-            candidates = (0, 3, 4, 5, 6, 8, 12, 64) if M1024 else (0, 16, 32, 64, 128)
+            candidates = (0, 4, 5, 6, 8, 12, 16, 64) if M1024 else (0, 16, 32, 64, 128)
         hist = self.arm_history
         times: dict[int, list[float]] = {c: [] for c in candidates}
         self.profile(True)
