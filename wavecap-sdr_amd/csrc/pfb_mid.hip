@@ -1083,6 +1083,105 @@ int spectrum_launch_t(const wh::SpectrumMidCall &c, hipStream_t st) {
     return WH_OK;
 }
 
+// ---- N = 4096 spectrum frames as 16 x 16 x 16 (the shaped instance took four trips through LDS -- radix 4 in registers,
+// then 8, 8, 4, 4 -- in one 1024-thread workgroup per CU: 3.3 TB/s).  Here a 256-thread workgroup owns a frame: thread
+// t = 16 n2 + n3 loads x[t + 256 n1], n1 < 16 (every load instruction of a wave reads 512 consecutive bytes), windows them and
+// does the radix-16 stage over n1 in registers; two more radix-16 stages follow through ONE padded LDS image
+// (n = 256 n1 + 16 n2 + n3, k = k1 + 16 k2 + 256 k3):
+//   image 1 [k1][t]       at k1 * 272 + t             (stage-1 results times W4096^(t k1))
+//   image 2 [k2][k1][n3]  at k2 * 272 + k1 * 17 + n3  (stage-2 results times W256^(n3 k2))
+// both conflict-free for their 8-byte accesses (272 = 16 mod 32 complex: the two k1 / k2 of a 32-lane group fall on the two
+// halves of the banks; 17 k1 mod 32 is distinct over k1 < 16 and leaves exactly the residues that + 16 fills).  Thread r of
+// stage 3 holds X[r + 256 k3]: every store instruction of a wave writes 64 consecutive bins.  The next frame's 16 samples
+// per thread are loaded right after the current ones are consumed and stay in flight across stages 2 and 3 (registers:
+// 30 stage-1 twiddles + 16 window values + 32 samples + 32 prefetched + the butterflies' temporaries = two workgroups per
+// CU; without the prefetch the kernel fits three per CU and measured 219 us per 2^26 samples against 175 with it -- memory
+// parallelism, not occupancy, is what a 12-byte-per-sample kernel needs; 246 us before).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void spectrum4096_kernel(SpecArgs a) {
+    constexpr int N = 4096, B1 = 272;
+    __shared__ __attribute__((aligned(16))) float2 img[16 * B1];
+    __shared__ float2 tw256[256];   // [k2][n3] = W256^(n3 k2)
+    const int t = threadIdx.x;
+    const float2 *twt = reinterpret_cast<const float2 *>(a.tw);
+    float2 tw1[15];
+#pragma unroll
+    for (int k1 = 1; k1 < 16; ++k1) tw1[k1 - 1] = twt[(t * k1) & (N - 1)];
+    float win[16];
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) win[n1] = a.window[t + 256 * n1];
+    tw256[t] = twt[(16 * (t & 15) * (t >> 4)) & (N - 1)];
+    __syncthreads();
+    float2 nx[16];                                  // the next frame's samples, in flight across stages 2 and 3
+    {
+        const float2 *px = reinterpret_cast<const float2 *>(a.x) + (size_t)blockIdx.x * a.frame_stride + t;
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) nx[n1] = px[256 * n1];
+    }
+    for (long long f = blockIdx.x; f < a.n_frames; f += gridDim.x) {
+        float2 v[16];
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) v[n1] = make_float2(nx[n1].x * win[n1], nx[n1].y * win[n1]);
+        {
+            long long fn = f + gridDim.x;           // (the last round re-reads its own frame: nobody uses it)
+            if (fn >= a.n_frames) fn = f;
+            const float2 *px = reinterpret_cast<const float2 *>(a.x) + (size_t)fn * a.frame_stride + t;
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) nx[n1] = px[256 * n1];
+        }
+        fft16(v);                                   // over n1: v[k1]
+        img[t] = v[0];
+#pragma unroll
+        for (int k1 = 1; k1 < 16; ++k1) img[k1 * B1 + t] = cmul(v[k1], tw1[k1 - 1]);
+        __syncthreads();
+        {
+            const int k1 = t >> 4, n3 = t & 15;
+            const float2 *src = img + k1 * B1 + n3;
+#pragma unroll
+            for (int n2 = 0; n2 < 16; ++n2) v[n2] = src[16 * n2];
+            fft16(v);                               // over n2: v[k2]
+            __syncthreads();                        // image 1 has been read by everybody: image 2 overwrites it
+            float2 *dst = img + k1 * 17 + n3;
+            dst[0] = v[0];
+#pragma unroll
+            for (int k2 = 1; k2 < 16; ++k2) dst[k2 * B1] = cmul(v[k2], tw256[k2 * 16 + n3]);
+        }
+        __syncthreads();
+        {
+            const float2 *row = img + (t >> 4) * B1 + (t & 15) * 17;   // k2 = t >> 4, k1 = t & 15
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = row[j];
+        }
+        __syncthreads();                            // image 2 has been read: the next frame's image 1 may land
+        fft16(v);                                   // over n3: v[k3] = X[t + 256 k3]
+        float *o = a.out + (size_t)f * N;
+#pragma unroll
+        for (int k3 = 0; k3 < 16; ++k3) {
+            // |X| + 1e-10 >= 1e-10 is a normal float: v_sqrt_f32 / v_log_f32 (1 ulp each; 20 log10 m = 20 log10(2) log2 m)
+            const float mag = __builtin_amdgcn_sqrtf(v[k3].x * v[k3].x + v[k3].y * v[k3].y) + 1e-10f;
+            o[(t + 256 * k3 + N / 2) & (N - 1)] = 6.02059991327962390427f * __builtin_amdgcn_logf(mag);
+        }
+    }
+}
+
+int spectrum4096_launch(const wh::SpectrumMidCall &c, hipStream_t st) {
+    static int wg_per_cu = 0;
+    if (wg_per_cu == 0) {
+        int nb = 0;
+        WH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(spectrum4096_kernel), 256, 0));
+        wg_per_cu = nb > 0 ? nb : 1;
+    }
+    SpecArgs a;
+    a.x = reinterpret_cast<const v2f *>(c.x); a.frame_stride = c.frame_stride; a.out = c.out; a.sink = c.sink;
+    a.window = c.window; a.tw = c.tw; a.n_frames = c.n_frames;
+    // whole rounds: every workgroup walks the same number of frames (a partial last round costs a full one)
+    const long long slots = (long long)c.cu_count * wg_per_cu;
+    const long long rounds = (c.n_frames + slots - 1) / slots;
+    const long long grid = (c.n_frames + rounds - 1) / rounds;
+    hipLaunchKernelGGL(spectrum4096_kernel, dim3((unsigned)grid), dim3(256), 0, st, a);
+    WH_LAUNCH_CHECK();
+    return WH_OK;
+}
+
 }  // namespace
 
 #ifdef WH_DIAG
@@ -1142,10 +1241,10 @@ int pfb_mid_launch(int M, int T, const PfbMidCall &c, hipStream_t st, long long 
     X(256, 4, 4, 0, 3, 8, 1, 0, 0, 0, 1) \
     X(512, 2, 4, 0, 3, 16, 2, 0, 0, 0, 1) \
     X(1024, 1, 4, 0, 3, 32, 2, 0, 0, 0, 1) \
-    X(2048, 1, 4, 0, 2, 64, 1, 0, 0, 0, 1) \
-    X(4096, 1, 2, 0, 2, 1024, 1, 0, 0, 0, 1)
+    X(2048, 1, 4, 0, 2, 64, 1, 0, 0, 0, 1)
 
 bool spectrum_mid_supported(int N) {
+    if (N == 4096) return true;   // spectrum4096_kernel
 #define X(N_, R_, GH_, NWF_, WPE_, PB_, PADN_, IMGX_, TREG_, LSP_, R8_) if (N == N_) return true;
     WH_SPEC_CONFIGS(X)
 #undef X
@@ -1155,6 +1254,7 @@ bool spectrum_mid_supported(int N) {
 int spectrum_mid_launch(int N, const SpectrumMidCall &c, hipStream_t st) {
     if (!c.sink || c.sink_elems < (size_t)N || !c.out)
         return set_err(WH_E_ARG, "spectrum_mid_launch: null output, or sink row missing / shorter than N=%d", N);
+    if (N == 4096) return spectrum4096_launch(c, st);
 #define X(N_, R_, GH_, NWF_, WPE_, PB_, PADN_, IMGX_, TREG_, LSP_, R8_) \
     if (N == N_) return spectrum_launch_t<MidCfg<N_, 1, R_, GH_, NWF_, WPE_, PB_, PADN_, IMGX_, TREG_, LSP_, R8_>>(c, st);
     WH_SPEC_CONFIGS(X)
