@@ -91,6 +91,59 @@ struct PfbFastArgs {
 // range are loaded by both at about the same time, so the second load is an L2 hit (same XCD: chunked mapping).  Walking
 // every run upwards the two loads are a whole run apart in time (all resident workgroups are in phase), further than the
 // 4 MB L2 reaches: the halo was fetched through the fabric a second time (FETCH_SIZE 1.45 x the input at 20-hop runs).
+// Packed complex arithmetic of the tuned kernel: every line is ONE v_pk_* instruction (swaps, broadcasts and sign patterns fold
+// into op_sel / constant operands).  The float2 helpers of wh_common.h cost ~130 register moves per group of four hops on top
+// of their arithmetic (pairs re-assembled for every +-i rotation and complex product); at three waves per SIMD the kernel's
+// compute-side floor is VALU issue, so they count.
+typedef float p2f __attribute__((ext_vector_type(2)));
+#define P_SW(a) __builtin_shufflevector(a, a, 1, 0)
+#define P_XX(a) __builtin_shufflevector(a, a, 0, 0)
+#define P_YY(a) __builtin_shufflevector(a, a, 1, 1)
+#define P_FMA(a, b, c) __builtin_elementwise_fma(a, b, c)
+#define P_PMI(x, d) P_FMA(P_SW(d), (p2f{1.f, -1.f}), x)    // x + (-i) d
+#define P_MMI(x, d) P_FMA(P_SW(d), (p2f{-1.f, 1.f}), x)    // x - (-i) d
+__device__ __forceinline__ p2f pcmul(p2f a, p2f w) {        // a * w, three instructions
+    const p2f t = P_XX(a) * w;
+    const p2f s = P_YY(a) * p2f{-1.f, 1.f};
+    return P_FMA(s, P_SW(w), t);
+}
+__device__ __forceinline__ p2f pcmulc(p2f a, float wx, float wy) {   // a * (wx + i wy), compile-time constant: two instructions
+    return P_FMA(P_YY(a), (p2f{-wy, wx}), (P_XX(a) * p2f{wx, wy}));
+}
+__device__ __forceinline__ void pfft4(p2f &a0, p2f &a1, p2f &a2, p2f &a3) {   // forward radix 4, natural order (same bits as fft4)
+    const p2f s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, d13 = a1 - a3;
+    a0 = s02 + s13;
+    a2 = s02 - s13;
+    a1 = P_PMI(d02, d13);
+    a3 = P_MMI(d02, d13);
+}
+__device__ __forceinline__ void pfft16(p2f (&v)[16]) {      // forward 16-point transform in place, natural order in and out
+    constexpr float C1 = 0.92387953251128673848f, S1 = 0.38268343236508978178f, R2 = 0.70710678118654752440f;
+#pragma unroll
+    for (int na = 0; na < 4; ++na) pfft4(v[na], v[na + 4], v[na + 8], v[na + 12]);
+    // v[na + 4 kb] = Y[na][kb] times W16^(na kb)
+    v[5] = pcmulc(v[5], C1, -S1);                       // W^1
+    v[9] = P_PMI(v[9], v[9]) * p2f{R2, R2};             // W^2 = R2 (1 - i)
+    v[13] = pcmulc(v[13], S1, -C1);                     // W^3
+    v[6] = P_PMI(v[6], v[6]) * p2f{R2, R2};             // W^2
+    v[10] = P_SW(v[10]) * p2f{1.f, -1.f};               // W^4 = -i
+    v[14] = P_MMI(v[14], v[14]) * p2f{-R2, -R2};        // W^6 = -R2 (1 + i)
+    v[7] = pcmulc(v[7], S1, -C1);                       // W^3
+    v[11] = P_MMI(v[11], v[11]) * p2f{-R2, -R2};        // W^6
+    v[15] = pcmulc(v[15], -C1, S1);                     // W^9
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) pfft4(v[4 * kb], v[4 * kb + 1], v[4 * kb + 2], v[4 * kb + 3]);
+    // v[ka + 4 kb] = X[4 ka + kb]: transpose to natural order (register renaming)
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = a + 1; b < 4; ++b) {
+            const p2f tmp = v[a + 4 * b];
+            v[a + 4 * b] = v[b + 4 * a];
+            v[b + 4 * a] = tmp;
+        }
+}
+
 template <int FMT, bool GLDS, bool STATS, bool W3>
 struct Pfb1024Lds {
     static constexpr int LDS_HOP = W3 ? 1088 : 1152;
@@ -202,17 +255,12 @@ __device__ __forceinline__ void pfb1024_body(const PfbFastArgs &a, float2 *lds, 
                 p2 = __builtin_elementwise_fma(WH_V2(wA[i + 9 - j]), WH_TAP(2, j), p2);   // k = t+512
                 p3 = __builtin_elementwise_fma(WH_V2(wB[i + 9 - j]), WH_TAP(3, j), p3);   // k = t+768
             }
-            float2 y0 = make_float2(p0.x, p0.y), y1 = make_float2(p1.x, p1.y), y2 = make_float2(p2.x, p2.y),
-                   y3 = make_float2(p3.x, p3.y);
-            fft4(y0, y1, y2, y3);  // A[k1], n1 = k/256
-            y1 = cmul(y1, tw1);
-            y2 = cmul(y2, tw2);
-            y3 = cmul(y3, tw3);
-            float2 *L = lds + i * LDS_HOP;
-            L[t] = y0;
-            L[LDS1_K1 + t] = y1;
-            L[2 * LDS1_K1 + t] = y2;
-            L[3 * LDS1_K1 + t] = y3;
+            pfft4(p0, p1, p2, p3);  // A[k1], n1 = k/256
+            p2f *L = reinterpret_cast<p2f *>(lds + i * LDS_HOP);
+            L[t] = p0;
+            L[LDS1_K1 + t] = pcmul(p1, p2f{tw1.x, tw1.y});
+            L[2 * LDS1_K1 + t] = pcmul(p2, p2f{tw2.x, tw2.y});
+            L[3 * LDS1_K1 + t] = pcmul(p3, p2f{tw3.x, tw3.y});
         }
         // slide the windows, then issue the next group's loads into the freed slots (the tail walking up, the head walking down)
         if (DIR > 0) {
@@ -256,38 +304,36 @@ __device__ __forceinline__ void pfb1024_body(const PfbFastArgs &a, float2 *lds, 
         if (GLDS && PRE_SINGLE) issue_dma();
         // ---- stage 2 (radix-16 over n2) : wave = hop, lane = (k1, n3) ------------------------
         {
-            float2 *L = lds + wave * LDS_HOP;
+            p2f *L = reinterpret_cast<p2f *>(lds + wave * LDS_HOP);
             const int k1 = lane >> 4, n3 = lane & 15;
-            float2 v[16];
+            p2f v[16];
             {   // (forcing 16 ds_read_b64 through inline asm instead of hipcc's 8 ds_read2_b64 measured no gain)
-                const float2 *src = L + k1 * LDS1_K1 + n3;
+                const p2f *src = L + k1 * LDS1_K1 + n3;
 #pragma unroll
                 for (int n2 = 0; n2 < 16; ++n2) v[n2] = src[n2 * 16];
             }
-            fft16(v);
+            pfft16(v);
             // twiddle W256^(n3*k2) and store to image 2 (same wave only: no barrier needed,
             // every lane's reads above were issued before these writes)
             __builtin_amdgcn_wave_barrier();
-            float2 *dst = L + k1 * LDS2_ROW + n3;
+            p2f *dst = L + k1 * LDS2_ROW + n3;
+            const p2f *twp = reinterpret_cast<const p2f *>(tw256);
             dst[0] = v[0];
 #pragma unroll
-            for (int k2 = 1; k2 < 16; ++k2) {
-                float2 w = tw256[k2 * 16 + n3];
-                dst[k2 * 4 * LDS2_ROW] = cmul(v[k2], w);
-            }
+            for (int k2 = 1; k2 < 16; ++k2) dst[k2 * 4 * LDS2_ROW] = pcmul(v[k2], twp[k2 * 16 + n3]);
         }
         // ---- stage 3 (radix-16 over n3) : lane = k1 + 4*k2, row = lane ------------------------
         __builtin_amdgcn_wave_barrier();
         {
             float2 *L = lds + wave * LDS_HOP;
-            float2 v[16];
+            p2f v[16];
             // 8 x ds_read_b128 by inline asm: written as float4 loads, hipcc scalarises them into
             // 16 ds_read2_b32 (real/imag de-interleaved), which at the 144-byte row stride is a 4-way
             // bank conflict (measured: SQ_LDS_BANK_CONFLICT > SQ_ACTIVE_INST_LDS).  b128 reads of the
             // padded rows are conflict-free.  The asm loads are waited for explicitly (lgkmcnt).
             if (W3) {
                 // rows 17 complex apart: 8-byte reads, conflict-free (34 l mod 64 distinct over 32 lanes)
-                const float2 *src = L + lane * LDS2_ROW;
+                const p2f *src = reinterpret_cast<const p2f *>(L) + lane * LDS2_ROW;
 #pragma unroll
                 for (int j = 0; j < 16; ++j) v[j] = src[j];
             } else {
@@ -307,21 +353,24 @@ __device__ __forceinline__ void pfb1024_body(const PfbFastArgs &a, float2 *lds, 
                              : "v"(addr)
                              : "memory");
                 __builtin_amdgcn_sched_barrier(0);
-                v[0] = make_float2(r0.x, r0.y);   v[1] = make_float2(r0.z, r0.w);
-                v[2] = make_float2(r1.x, r1.y);   v[3] = make_float2(r1.z, r1.w);
-                v[4] = make_float2(r2.x, r2.y);   v[5] = make_float2(r2.z, r2.w);
-                v[6] = make_float2(r3.x, r3.y);   v[7] = make_float2(r3.z, r3.w);
-                v[8] = make_float2(r4.x, r4.y);   v[9] = make_float2(r4.z, r4.w);
-                v[10] = make_float2(r5.x, r5.y);  v[11] = make_float2(r5.z, r5.w);
-                v[12] = make_float2(r6.x, r6.y);  v[13] = make_float2(r6.z, r6.w);
-                v[14] = make_float2(r7.x, r7.y);  v[15] = make_float2(r7.z, r7.w);
+                v[0] = p2f{r0.x, r0.y};   v[1] = p2f{r0.z, r0.w};
+                v[2] = p2f{r1.x, r1.y};   v[3] = p2f{r1.z, r1.w};
+                v[4] = p2f{r2.x, r2.y};   v[5] = p2f{r2.z, r2.w};
+                v[6] = p2f{r3.x, r3.y};   v[7] = p2f{r3.z, r3.w};
+                v[8] = p2f{r4.x, r4.y};   v[9] = p2f{r4.z, r4.w};
+                v[10] = p2f{r5.x, r5.y};  v[11] = p2f{r5.z, r5.w};
+                v[12] = p2f{r6.x, r6.y};  v[13] = p2f{r6.z, r6.w};
+                v[14] = p2f{r7.x, r7.y};  v[15] = p2f{r7.z, r7.w};
             }
-            fft16(v);
+            pfft16(v);
+            float2 vf[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) vf[j] = make_float2(v[j].x, v[j].y);
             if (STATS) {
                 // lane l holds X[l + 64 j] of hop h + wave: their powers go to the wave's own (finished) image, [channel]
                 float *pwv = reinterpret_cast<float *>(L);
 #pragma unroll
-                for (int j = 0; j < 16; ++j) pwv[lane + 64 * j] = stat_power(v[j].x, v[j].y);
+                for (int j = 0; j < 16; ++j) pwv[lane + 64 * j] = stat_power(vf[j].x, vf[j].y);
             } else if (ST8) {
                 // 8-byte stores, no lane exchange: 16 store instructions of 512 contiguous bytes per wave.  At three
                 // workgroups per CU the exchange (48 selects + 16 ds_bpermute per group; as 32 v_cndmask_b32_dpp it measured
@@ -330,9 +379,9 @@ __device__ __forceinline__ void pfb1024_body(const PfbFastArgs &a, float2 *lds, 
 #pragma unroll
                 for (int j = 0; j < 16; ++j)
 #ifdef WH_DIAG
-                    if (!(a.ablate & 1) || v[j].x == 1.2345e30f)
+                    if (!(a.ablate & 1) || vf[j].x == 1.2345e30f)
 #endif
-                    o[64 * j] = v[j];
+                    o[64 * j] = vf[j];
             } else {
                 // 16-byte stores (+2.3 % over 8-byte ones): lanes 2m / 2m+1 swap half of their outputs so that
                 // the even lane owns (X[2m + 64 j], X[2m+1 + 64 j]) for j < 8 and the odd lane the pair for j >= 8
@@ -340,12 +389,12 @@ __device__ __forceinline__ void pfb1024_body(const PfbFastArgs &a, float2 *lds, 
                 float4 *o4 = reinterpret_cast<float4 *>(a.out + (h + wave) * FM + (lane & ~1) + (even ? 0 : 512));
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    float2 snd = even ? v[j + 8] : v[j];
+                    float2 snd = even ? vf[j + 8] : vf[j];
                     float2 rcv;
                     rcv.x = __shfl_xor(snd.x, 1);
                     rcv.y = __shfl_xor(snd.y, 1);
-                    float2 lo = even ? v[j] : rcv;
-                    float2 hi = even ? rcv : v[j + 8];
+                    float2 lo = even ? vf[j] : rcv;
+                    float2 hi = even ? rcv : vf[j + 8];
 #ifdef WH_DIAG
                     if (!(a.ablate & 1) || lo.x == 1.2345e30f)
 #endif
