@@ -197,6 +197,9 @@ int wh_pfb_tune(wh_pfb *p, int key, int value);
  * the most recent one. */
 int wh_pfb_profile(wh_pfb *p, int enable);
 int wh_pfb_kernel_ms(wh_pfb *p, float *ms);
+/* the same for the launch `back` launches before the most recent one (0 = most recent; the handle keeps the event pairs of
+ * its last 64 profiled launches): a caller times every launch of a run without synchronising between them */
+int wh_pfb_kernel_ms_back(wh_pfb *p, int back, float *ms);
 /* extract_channel, channelizer.py:144-158: d_col[h] = d_out[h][idx] */
 int wh_pfb_extract_channel(const float *d_out, size_t hops, int channel_count, int idx, float *d_col,
                            void *stream);

@@ -1028,8 +1028,13 @@ struct wh_pfb {
     bool run_ok = false;        // M, T fit pfb_run_kernel
     bool mid_ok = false;        // a compile-time-shaped instance exists (pfb_mid.hip)
     bool prof = false;          // bracket the fused kernel with events (bench roofline)
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool ev_valid = false;
+    // profiling events: a ring of the last EVR launches' (begin, end) pairs, so that a caller can time EVERY launch of a
+    // run and read the durations afterwards -- without a host synchronisation between launches (wh_pfb_kernel_ms_back)
+    static constexpr int EVR = 64;
+    hipEvent_t ev0[EVR] = {}, ev1[EVR] = {};
+    int ev_cur = 0, ev_last = -1, ev_n = 0;
+    int ev_begin() { ev_cur = (ev_last + 1) % EVR; return ev_cur; }
+    void ev_end() { ev_last = ev_cur; if (ev_n < EVR) ++ev_n; }
 };
 
 extern "C" int wh_pfb_create(wh_pfb **out, int M, int T, const double *h_arms) {
@@ -1089,8 +1094,10 @@ extern "C" void wh_pfb_destroy(wh_pfb *p) {
     (void)hipFree(p->d_sink);
     (void)hipFree(p->d_edge);
     (void)hipFree(p->d_stats_ws);
-    if (p->ev0) (void)hipEventDestroy(p->ev0);
-    if (p->ev1) (void)hipEventDestroy(p->ev1);
+    for (int i = 0; i < wh_pfb::EVR; ++i) {
+        if (p->ev0[i]) (void)hipEventDestroy(p->ev0[i]);
+        if (p->ev1[i]) (void)hipEventDestroy(p->ev1[i]);
+    }
     delete p;
 }
 
@@ -1130,22 +1137,28 @@ extern "C" int wh_pfb_tune(wh_pfb *p, int key, int value) {
 
 extern "C" int wh_pfb_profile(wh_pfb *p, int enable) {
     if (!p) return set_err(WH_E_ARG, "wh_pfb_profile: null handle");
-    if (enable && !p->ev0) {
-        WH_HIP(hipEventCreate(&p->ev0));
-        WH_HIP(hipEventCreate(&p->ev1));
+    if (enable && !p->ev0[0]) {
+        for (int i = 0; i < wh_pfb::EVR; ++i) {
+            WH_HIP(hipEventCreate(&p->ev0[i]));
+            WH_HIP(hipEventCreate(&p->ev1[i]));
+        }
     }
     p->prof = enable != 0;
-    p->ev_valid = false;
+    p->ev_n = 0;
+    p->ev_last = -1;
     return WH_OK;
 }
 
-extern "C" int wh_pfb_kernel_ms(wh_pfb *p, float *ms) {
+extern "C" int wh_pfb_kernel_ms_back(wh_pfb *p, int back, float *ms) {
     if (!p || !ms) return set_err(WH_E_ARG, "wh_pfb_kernel_ms: null");
-    if (!p->ev_valid) return set_err(WH_E_ARG, "wh_pfb_kernel_ms: no profiled fused-kernel launch yet");
-    WH_HIP(hipEventSynchronize(p->ev1));
-    WH_HIP(hipEventElapsedTime(ms, p->ev0, p->ev1));
+    if (back < 0 || back >= p->ev_n) return set_err(WH_E_ARG, "wh_pfb_kernel_ms: no profiled launch %d back (have %d)", back, p->ev_n);
+    const int i = ((p->ev_last - back) % wh_pfb::EVR + wh_pfb::EVR) % wh_pfb::EVR;
+    WH_HIP(hipEventSynchronize(p->ev1[i]));
+    WH_HIP(hipEventElapsedTime(ms, p->ev0[i], p->ev1[i]));
     return WH_OK;
 }
+
+extern "C" int wh_pfb_kernel_ms(wh_pfb *p, float *ms) { return wh_pfb_kernel_ms_back(p, 0, ms); }
 
 extern "C" size_t wh_pfb_hops(const wh_pfb *p, size_t n) {
     if (!p || n < (size_t)p->M) return 0;
@@ -1240,11 +1253,11 @@ static int pfb_run_fmt(wh_pfb *p, const void *d_iq, int fmt, size_t n, float *d_
 #ifdef WH_DIAG
         c.stats_only = p->ablate << 8;
 #endif
-        if (p->prof) WH_HIP(hipEventRecord(p->ev0, st));
+        if (p->prof) WH_HIP(hipEventRecord(p->ev0[p->ev_begin()], st));
         if ((rc = pfb_mid_launch(p->M, p->T, c, st)) != WH_OK) return rc;
         if (p->prof) {
-            WH_HIP(hipEventRecord(p->ev1, st));
-            p->ev_valid = true;
+            WH_HIP(hipEventRecord(p->ev1[p->ev_cur], st));
+            p->ev_end();
         }
         p->cur ^= 1;
         return WH_OK;
@@ -1296,7 +1309,7 @@ static int pfb_run_fmt(wh_pfb *p, const void *d_iq, int fmt, size_t n, float *d_
         const long long waves = (nh + hpw - 1) / hpw;
         const unsigned nwg = (unsigned)((waves + 3) / 4);
         const size_t smem = (size_t)4 * rgh * p->M * sizeof(float2);   // images; twiddles and taps are static LDS
-        if (p->prof) WH_HIP(hipEventRecord(p->ev0, st));
+        if (p->prof) WH_HIP(hipEventRecord(p->ev0[p->ev_begin()], st));
         if (cpl == 1) {
             if (fmt == 1) hipLaunchKernelGGL((pfb_run_kernel<1, 1, 2>), dim3(nwg), dim3(256), smem, st, a);
             else hipLaunchKernelGGL((pfb_run_kernel<0, 1, 2>), dim3(nwg), dim3(256), smem, st, a);
@@ -1306,8 +1319,8 @@ static int pfb_run_fmt(wh_pfb *p, const void *d_iq, int fmt, size_t n, float *d_
         }
         WH_LAUNCH_CHECK();
         if (p->prof) {
-            WH_HIP(hipEventRecord(p->ev1, st));
-            p->ev_valid = true;
+            WH_HIP(hipEventRecord(p->ev1[p->ev_cur], st));
+            p->ev_end();
         }
     }
     if (fast && H > 8) {
@@ -1347,7 +1360,7 @@ static int pfb_run_fmt(wh_pfb *p, const void *d_iq, int fmt, size_t n, float *d_
 #ifdef WH_DIAG
             a.ablate = p->ablate;
 #endif
-            if (p->prof) WH_HIP(hipEventRecord(p->ev0, st));
+            if (p->prof) WH_HIP(hipEventRecord(p->ev0[p->ev_begin()], st));
             // prefetch path: int16 input through the LDS DMA (16 bytes per lane instead of 4: 1.30 -> 1.15 ms per 2^28
             // samples), complex64 input through registers (the DMA detour costs it 4 %); WH_PFB_VARIANT = 1 / 3 forces
             // the register / DMA form for both
@@ -1370,8 +1383,8 @@ static int pfb_run_fmt(wh_pfb *p, const void *d_iq, int fmt, size_t n, float *d_
                 hipLaunchKernelGGL(pfb1024_kernel<0>, dim3((unsigned)nwg), dim3(256), 0, st, a);
             WH_LAUNCH_CHECK();
             if (p->prof) {
-                WH_HIP(hipEventRecord(p->ev1, st));
-                p->ev_valid = true;
+                WH_HIP(hipEventRecord(p->ev1[p->ev_cur], st));
+                p->ev_end();
             }
         }
     }
@@ -1515,13 +1528,13 @@ extern "C" int wh_pfb_run_stats(wh_pfb *p, const void *d_iq, int input_format, s
                 p->stats_ws_rows = (size_t)nwg;
             }
             a.stats_ws = p->d_stats_ws;
-            if (p->prof) WH_HIP(hipEventRecord(p->ev0, st));
+            if (p->prof) WH_HIP(hipEventRecord(p->ev0[p->ev_begin()], st));
             if (input_format == 1) hipLaunchKernelGGL((pfb1024_kernel<1, true, true>), dim3((unsigned)nwg), dim3(256), 0, st, a);
             else hipLaunchKernelGGL((pfb1024_kernel<0, false, true>), dim3((unsigned)nwg), dim3(256), 0, st, a);
             WH_LAUNCH_CHECK();
             if (p->prof) {
-                WH_HIP(hipEventRecord(p->ev1, st));
-                p->ev_valid = true;
+                WH_HIP(hipEventRecord(p->ev1[p->ev_cur], st));
+                p->ev_end();
             }
             if ((rc = pfb_stats_rows_reduce(p->d_stats_ws, (int)nwg, -1, p->M, (double)(n_groups * GH), d_stats, acc, st)) != WH_OK)
                 return rc;
@@ -1558,11 +1571,11 @@ extern "C" int wh_pfb_run_stats(wh_pfb *p, const void *d_iq, int input_format, s
         p->stats_ws_rows = (size_t)grid;
     }
     c.stats_ws = p->d_stats_ws;
-    if (p->prof) WH_HIP(hipEventRecord(p->ev0, st));
+    if (p->prof) WH_HIP(hipEventRecord(p->ev0[p->ev_begin()], st));
     if ((rc = pfb_mid_launch(p->M, p->T, c, st)) != WH_OK) return rc;
     if (p->prof) {
-        WH_HIP(hipEventRecord(p->ev1, st));
-        p->ev_valid = true;
+        WH_HIP(hipEventRecord(p->ev1[p->ev_cur], st));
+        p->ev_end();
     }
     p->cur ^= 1;
     return WH_OK;

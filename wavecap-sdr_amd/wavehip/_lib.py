@@ -125,6 +125,7 @@ PROTOTYPES = {
     "wh_pfb_tune": (c_int, [c_void_p, c_int, c_int]),
     "wh_pfb_profile": (c_int, [c_void_p, c_int]),
     "wh_pfb_kernel_ms": (c_int, [c_void_p, C.POINTER(c_float)]),
+    "wh_pfb_kernel_ms_back": (c_int, [c_void_p, c_int, C.POINTER(c_float)]),
     "wh_pfb_extract_channel": (c_int, [c_void_p, c_size_t, c_int, c_int, c_void_p, c_void_p]),
     "wh_pfb_channel_stats": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_void_p]),
     "wh_diag_stream_1r2w": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -152,9 +152,11 @@ class PolyphaseChannelizer:
     def profile(self, enable: bool = True) -> None:
         _lib.check(_lib.lib.wh_pfb_profile(self._h, 1 if enable else 0), "wh_pfb_profile")
 
-    def last_kernel_ms(self) -> float:
+    def last_kernel_ms(self, back: int = 0) -> float:
+        """Duration of the main filterbank kernel of the most recent profiled launch (back = 0) or of the launch `back`
+        launches earlier (the handle keeps 64): waits for that launch only."""
         ms = C.c_float()
-        _lib.check(_lib.lib.wh_pfb_kernel_ms(self._h, C.byref(ms)), "wh_pfb_kernel_ms")
+        _lib.check(_lib.lib.wh_pfb_kernel_ms_back(self._h, int(back), C.byref(ms)), "wh_pfb_kernel_ms_back")
         return float(ms.value)
 
     def channel_stats_device(self, out_dev, stats=None, accumulate: bool = False):
