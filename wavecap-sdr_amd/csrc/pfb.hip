@@ -1033,6 +1033,10 @@ struct wh_pfb {
     static constexpr int EVR = 64;
     hipEvent_t ev0[EVR] = {}, ev1[EVR] = {};
     int ev_cur = 0, ev_last = -1, ev_n = 0;
+    // side stream of the fast path: the head / tail hops (per-hop kernel) and the history update are independent of the fused
+    // kernel and run beside it (fork / join by events on the caller's stream: still enqueue-only, and capturable)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int ev_begin() { ev_cur = (ev_last + 1) % EVR; return ev_cur; }
     void ev_end() { ev_last = ev_cur; if (ev_n < EVR) ++ev_n; }
 };
@@ -1069,6 +1073,14 @@ extern "C" int wh_pfb_create(wh_pfb **out, int M, int T, const double *h_arms) {
     WH_HIP(hipGetDevice(&dev));
     WH_HIP(hipGetDeviceProperties(&prop, dev));
     p->cu_count = prop.multiProcessorCount;
+    if (M == FM && T == FT) {
+        if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess) p->side = nullptr;
+        if (p->side && (hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                        hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) != hipSuccess)) {
+            (void)hipStreamDestroy(p->side);
+            p->side = nullptr;
+        }
+    }
     WH_HIP(hipMalloc(&p->d_arms, arms.size() * sizeof(float)));
     WH_HIP(hipMalloc(&p->d_tw, tw.size() * sizeof(float2)));
     WH_HIP(hipMalloc(&p->d_hist[0], (size_t)M * T * sizeof(float2)));
@@ -1097,6 +1109,12 @@ extern "C" void wh_pfb_destroy(wh_pfb *p) {
     for (int i = 0; i < wh_pfb::EVR; ++i) {
         if (p->ev0[i]) (void)hipEventDestroy(p->ev0[i]);
         if (p->ev1[i]) (void)hipEventDestroy(p->ev1[i]);
+    }
+    if (p->side) {
+        (void)hipStreamSynchronize(p->side);
+        (void)hipStreamDestroy(p->side);
+        (void)hipEventDestroy(p->ev_fork);
+        (void)hipEventDestroy(p->ev_join);
     }
     delete p;
 }
@@ -1264,6 +1282,15 @@ static int pfb_run_fmt(wh_pfb *p, const void *d_iq, int fmt, size_t n, float *d_
     }
     const bool run = !fast && p->run_ok && p->path != 1;
     long long head = (fast || run) ? (H < 8 ? H : 8) : H;
+    // long calls of the fast path: the per-hop kernel (head / tail hops: 11 workgroups, ~16 us of dependent passes) and the
+    // history update go to the handle's side stream and run BESIDE the fused kernel instead of before / after it
+    const bool fork = fast && p->side && (H - 8) / GH >= 8LL * p->cu_count;
+    hipStream_t sg = st;
+    if (fork) {
+        WH_HIP(hipEventRecord(p->ev_fork, st));
+        WH_HIP(hipStreamWaitEvent(p->side, p->ev_fork, 0));
+        sg = p->side;
+    }
     {
         // head hops (need the carried history) + the <= 3 ragged tail hops of the fast path, one launch
         long long tail0 = 0, tailn = 0;
@@ -1271,7 +1298,14 @@ static int pfb_run_fmt(wh_pfb *p, const void *d_iq, int fmt, size_t n, float *d_
             tail0 = 8 + ((H - 8) / GH) * GH;
             tailn = H - tail0;
         }
-        if ((rc = launch_generic(p, d_iq, fmt, d_out, 0, head, st, tail0, tailn)) != WH_OK) return rc;
+        if ((rc = launch_generic(p, d_iq, fmt, d_out, 0, head, sg, tail0, tailn)) != WH_OK) return rc;
+    }
+    const int hist_nxt = p->cur ^ 1;
+    if (fork) {
+        hipLaunchKernelGGL(pfb_hist_kernel, dim3((p->M * p->T + 255) / 256), dim3(256), 0, sg, d_iq, fmt, p->d_hist[p->cur],
+                           p->d_hist[hist_nxt], p->M, p->T, H);
+        WH_LAUNCH_CHECK();
+        WH_HIP(hipEventRecord(p->ev_join, sg));
     }
     if (run && H > 8) {
         PfbRunArgs a;
@@ -1389,11 +1423,15 @@ static int pfb_run_fmt(wh_pfb *p, const void *d_iq, int fmt, size_t n, float *d_
         }
     }
     // carry the history
-    int nxt = p->cur ^ 1;
-    int tot = p->M * p->T;
-    hipLaunchKernelGGL(pfb_hist_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, d_iq, fmt, p->d_hist[p->cur],
-                       p->d_hist[nxt], p->M, p->T, H);
-    WH_LAUNCH_CHECK();
+    int nxt = hist_nxt;
+    if (fork) {
+        WH_HIP(hipStreamWaitEvent(st, p->ev_join, 0));   // join: everything of this call is ordered before what follows on st
+    } else {
+        int tot = p->M * p->T;
+        hipLaunchKernelGGL(pfb_hist_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, d_iq, fmt, p->d_hist[p->cur],
+                           p->d_hist[nxt], p->M, p->T, H);
+        WH_LAUNCH_CHECK();
+    }
     p->cur = nxt;
     return WH_OK;
 }
