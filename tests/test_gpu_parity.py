@@ -1144,6 +1144,37 @@ def test_a7_pfb_other_tap_counts_vs_oracle(wh, O, fs, bw, M, T):
     assert np.array_equal(ch.arm_history, ref.arm_history)
 
 
+def test_a7_pfb_kernel_time_ring(wh):
+    """wh_pfb_kernel_ms_back: the handle keeps the event pairs of its last 64 profiled launches, so a caller can time every
+    launch of a run without waiting between them (bench.py reads the timed steps' kernel durations after the timed region);
+    a launch further back than what was recorded is refused.  The long-call fast path runs the head / tail hops and the
+    history update on the handle's side stream beside the fused kernel: checked against the shaped kernel family (which
+    has no side stream) on the same calls, and for run-to-run equality."""
+    import torch
+
+    ch = wh.PolyphaseChannelizer(10_000_000, 9765)
+    ch.profile(True)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.view_as_complex(torch.randn(1024 * 4200 + 77, 2, device="cuda", generator=g).mul_(0.5))   # > 8 groups per CU: forks
+    outs = [ch.process_device(x[: 1024 * 4100 + 5]).clone(), ch.process_device(x[1024 * 4100 + 5:]).clone(), None]
+    ch.process_device(x[:1024 * 50])
+    t = [ch.last_kernel_ms(back=b) for b in range(3)]
+    assert all(v > 0 for v in t) and t[2] > t[0]          # the long first call is further back
+    with pytest.raises(RuntimeError):
+        ch.last_kernel_ms(back=3)
+    # the same calls through the shaped kernel family (one launch per call, no side stream): same numbers to the parity
+    # tolerance (the two factor their transforms differently), same carried history exactly; and the fork path twice: same bits
+    cut = 1024 * 4100 + 5
+    ref = wh.PolyphaseChannelizer(10_000_000, 9765).tune(path="shaped")
+    r0, r1 = ref.process_device(x[:cut]), ref.process_device(x[cut:])
+    for a, b in ((outs[0], r0), (outs[1], r1)):
+        assert a.shape == b.shape and float((a - b).abs().max() / b.abs().max()) <= TOL
+    again = wh.PolyphaseChannelizer(10_000_000, 9765)
+    assert torch.equal(again.process_device(x[:cut]), outs[0]) and torch.equal(again.process_device(x[cut:]), outs[1])
+    ref.process_device(x[:1024 * 50])
+    assert np.array_equal(ch.arm_history, ref.arm_history)
+
+
 def test_a7_pfb_prefetch_forms_agree(wh):
     """The fused 1024-channel kernel prefetches the next group's samples either into registers or through the LDS DMA with
     counted waits, at two or three workgroups per CU: tune(prefetch=1 / 3) are the two-workgroup forms, 7 / 5 the
