@@ -49,6 +49,17 @@ __device__ __forceinline__ float2 ld_iq(const void *p, long long i) {
     }
     return reinterpret_cast<const float2 *>(p)[i];
 }
+// the tuned kernel's loader: int16 samples come back UNSCALED (int16 -> float32 only) -- its taps carry the 1 / 32768 of
+// the A1 unpack rule instead.  Scaling by a power of two is exact on either factor and an FMA rounds once, so
+// fma(x / 32768, tap, acc) and fma(x, tap / 32768, acc) are the same bits: 16 multiplies per group and thread saved
+template <int FMT>
+__device__ __forceinline__ float2 ld_iq_raw(const void *p, long long i) {
+    if (FMT == 1) {
+        short2 v = reinterpret_cast<const short2 *>(p)[i];
+        return make_float2((float)v.x, (float)v.y);
+    }
+    return reinterpret_cast<const float2 *>(p)[i];
+}
 __device__ __forceinline__ float2 ld_iq_rt(const void *p, int fmt, long long i) {
     return fmt == 1 ? ld_iq<1>(p, i) : ld_iq<0>(p, i);
 }
@@ -188,8 +199,8 @@ __device__ __forceinline__ void pfb1024_body(const PfbFastArgs &a, float2 *lds, 
     const long long xp = (h - 8) * FHOP + t;
 #pragma unroll
     for (int i = 0; i < 9 + GH; ++i) {
-        wA[i] = ld_iq<FMT>(a.x, xp + i * FHOP);
-        wB[i] = ld_iq<FMT>(a.x, xp + i * FHOP + 256);
+        wA[i] = ld_iq_raw<FMT>(a.x, xp + i * FHOP);
+        wB[i] = ld_iq_raw<FMT>(a.x, xp + i * FHOP + 256);
     }
     // taps: arms[k][j] for k = t, t+256, t+512, t+768, kept as 18 register PAIRS (tap e = q * 9 + j is half e & 1 of pair
     // e / 2): the arm MAC below is packed -- (re, im) * tap as one v_pk_fma_f32 with the tap broadcast from its half of the
@@ -199,7 +210,8 @@ __device__ __forceinline__ void pfb1024_body(const PfbFastArgs &a, float2 *lds, 
 #pragma unroll
     for (int e = 0; e < 4 * FT; e += 2) {
         const int q0 = e / FT, j0 = e - q0 * FT, q1 = (e + 1) / FT, j1 = (e + 1) - q1 * FT;
-        tpr[e / 2] = v2f{a.arms[(t + 256 * q0) * FT + j0], a.arms[(t + 256 * q1) * FT + j1]};
+        constexpr float TS = FMT == 1 ? 1.0f / 32768.0f : 1.0f;   // int16 input: see ld_iq_raw
+        tpr[e / 2] = v2f{a.arms[(t + 256 * q0) * FT + j0] * TS, a.arms[(t + 256 * q1) * FT + j1] * TS};
     }
     tw256[t] = tw256_t;
     __syncthreads();
@@ -296,8 +308,8 @@ __device__ __forceinline__ void pfb1024_body(const PfbFastArgs &a, float2 *lds, 
             for (int i = 0; i < GH; ++i) {
                 long long blk = nblk + i;
                 blk = blk > a.max_block ? a.max_block : (DIR < 0 && blk < 0 ? 0 : blk);
-                wA[NEW0 + i] = ld_iq<FMT>(a.x, blk * FHOP + t);
-                wB[NEW0 + i] = ld_iq<FMT>(a.x, blk * FHOP + t + 256);
+                wA[NEW0 + i] = ld_iq_raw<FMT>(a.x, blk * FHOP + t);
+                wB[NEW0 + i] = ld_iq_raw<FMT>(a.x, blk * FHOP + t + 256);
             }
         }
         __syncthreads();
@@ -433,8 +445,8 @@ __device__ __forceinline__ void pfb1024_body(const PfbFastArgs &a, float2 *lds, 
                 if (FMT == 1) {
                     const short2 *p16 = reinterpret_cast<const short2 *>(pre);
                     const short2 va = p16[i * FHOP + t], vb = p16[i * FHOP + t + 256];
-                    wA[NEW0 + i] = make_float2((float)va.x * (1.0f / 32768.0f), (float)va.y * (1.0f / 32768.0f));
-                    wB[NEW0 + i] = make_float2((float)vb.x * (1.0f / 32768.0f), (float)vb.y * (1.0f / 32768.0f));
+                    wA[NEW0 + i] = make_float2((float)va.x, (float)va.y);   // (unscaled: the taps carry the 1 / 32768)
+                    wB[NEW0 + i] = make_float2((float)vb.x, (float)vb.y);
                 } else {
                     const float2 *p32 = reinterpret_cast<const float2 *>(pre);
                     wA[NEW0 + i] = p32[i * FHOP + t];
