@@ -215,6 +215,8 @@ __device__ __forceinline__ void pfb1024_body(const PfbFastArgs &a, float2 *lds, 
     }
     tw256[t] = tw256_t;
     __syncthreads();
+    const p2f tw1p = {tw1.x, tw1.y}, tw2p = {tw2.x, tw2.y}, tw3p = {tw3.x, tw3.y};
+    const p2f tw1r = {-tw1.y, tw1.x}, tw2r = {-tw2.y, tw2.x}, tw3r = {-tw3.y, tw3.x};
 
     StAcc sacc[STATS ? 4 : 1];
     if (STATS) {
@@ -270,9 +272,10 @@ __device__ __forceinline__ void pfb1024_body(const PfbFastArgs &a, float2 *lds, 
             pfft4(p0, p1, p2, p3);  // A[k1], n1 = k/256
             p2f *L = reinterpret_cast<p2f *>(lds + i * LDS_HOP);
             L[t] = p0;
-            L[LDS1_K1 + t] = pcmul(p1, p2f{tw1.x, tw1.y});
-            L[2 * LDS1_K1 + t] = pcmul(p2, p2f{tw2.x, tw2.y});
-            L[3 * LDS1_K1 + t] = pcmul(p3, p2f{tw3.x, tw3.y});
+            // a * w as two instructions: the rotated copy (-wy, wx) of each stage-1 twiddle is kept beside it (6 registers)
+            L[LDS1_K1 + t] = P_FMA(P_YY(p1), tw1r, (P_XX(p1) * tw1p));
+            L[2 * LDS1_K1 + t] = P_FMA(P_YY(p2), tw2r, (P_XX(p2) * tw2p));
+            L[3 * LDS1_K1 + t] = P_FMA(P_YY(p3), tw3r, (P_XX(p3) * tw3p));
         }
         // slide the windows, then issue the next group's loads into the freed slots (the tail walking up, the head walking down)
         if (DIR > 0) {
