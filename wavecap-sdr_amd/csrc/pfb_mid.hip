@@ -849,6 +849,7 @@ int g_diag_stamp_wg = 0;
 //     800: plan [8, 5, 5] waves 4 (R = 1, GH = 8: 482 -> 454 us against the 10-wave shape R = 3) lanes/hop 20 util 0.78 pass-util 0.62 last-pass lanes/hop 32 LDS 54320 B conflicts rd x1.59 wr x1.54
 //     960: plan [4, 4, 3, 5] waves 4 lanes/hop 40 util 0.94 pass-util 0.62 last-pass lanes/hop 64 LDS 46896 B conflicts rd x1.83 wr x1.69
 //    1280: plan [4, 4, 4, 5] waves 5 lanes/hop 64 util 1.00 pass-util 1.00 last-pass lanes/hop 64 LDS 57520 B conflicts rd x2.25 wr x1.50
+//          (held to 168 VGPRs since round 3: at 177 a CU took ONE five-wave workgroup; two of them: 497 -> 486 us per 2^26 samples)
 //    2048: plan [8, 8, 8] waves 8 lanes/hop 128 util 1.00 pass-util 1.00 last-pass lanes/hop 64 LDS 74624 B conflicts rd x2.00 wr x1.33
 //    4096: plan [8, 8, 4, 4] waves 16 lanes/hop 512 util 1.00 pass-util 1.00 last-pass lanes/hop 64 LDS 147456 B (20 register taps: the
 //          1024-thread workgroup has 128 registers per lane; one workgroup per CU) conflicts rd x3.75 wr x1.75
@@ -871,7 +872,7 @@ int g_diag_stamp_wg = 0;
     X(768, 1, 3, 0, 3, 48, 2, 0, 36, 0, 0) \
     X(800, 1, 8, 0, 2, 0, 0, 0, 36, 20, 1) \
     X(960, 1, 4, 0, 3, 5, 2, 4, 36, 40, 0) \
-    X(1280, 1, 5, 0, 2, 80, 2, 0, 36, 0, 0) \
+    X(1280, 1, 5, 0, 3, 80, 2, 0, 36, 0, 0) \
     X(2048, 1, 4, 0, 2, 64, 1, 0, 36, 0, 1) \
     X(4096, 1, 2, 0, 2, 1024, 1, 0, 20, 0, 1)
 
