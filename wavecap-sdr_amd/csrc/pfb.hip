@@ -5,7 +5,9 @@
 //   out[h][c] = sum_k y_h[k] * exp(-2 pi i k c / M)     (forward, unnormalised)
 //
 // Fast path (M = 1024, T = 9): one fused kernel, HBM traffic = read x once (+halo) and write
-// out once = 24 B per input sample.  A 256-thread workgroup walks a run of consecutive hops.
+// out once = 24 B per input sample.  A 256-thread workgroup walks a run of consecutive hops (default since round 3: three
+// workgroups per CU, runs of 16-48 hops dealt so that the chip sweeps one band of addresses, odd runs walked downwards so
+// that the halo is an L2 hit, the next group's samples prefetched by the LDS DMA -- see pfb1024_body).
 //   * arm MAC: thread t owns columns k0 = t and t+256 of the half-block; because block_g[k0+512]
 //     == block_{g+1}[k0], one sliding register window c_g = x[g*512+k0] serves both halves, so
 //     every input sample is loaded once per workgroup (coalesced 8 B/lane) and the 36 tap
@@ -1410,12 +1412,10 @@ static int pfb_run_fmt(wh_pfb *p, const void *d_iq, int fmt, size_t n, float *d_
             a.ablate = p->ablate;
 #endif
             if (p->prof) WH_HIP(hipEventRecord(p->ev0[p->ev_begin()], st));
-            // prefetch path: int16 input through the LDS DMA (16 bytes per lane instead of 4: 1.30 -> 1.15 ms per 2^28
-            // samples), complex64 input through registers (the DMA detour costs it 4 %); WH_PFB_VARIANT = 1 / 3 forces
-            // the register / DMA form for both
+            // kernel form (wh_pfb_tune PREFETCH): 0 / 5 = three workgroups per CU with the LDS-DMA prefetch (default, both input
+            // formats), 7 = three per CU with register prefetch, 1 / 3 = the two-workgroup forms of rounds 1-2 (register / DMA)
             const bool dma = p->variant == 3;
             if (p->variant == 0 || p->variant == 5 || p->variant == 7) {
-                // default (round 3): the three-workgroups-per-CU form with the LDS-DMA prefetch, both input formats   // three workgroups per CU: 5 = LDS-DMA prefetch, 7 = register prefetch
                 if (p->variant != 7) {
                     if (fmt == 1) hipLaunchKernelGGL((pfb1024_kernel<1, true, false, true>), dim3((unsigned)nwg), dim3(256), 0, st, a);
                     else hipLaunchKernelGGL((pfb1024_kernel<0, true, false, true>), dim3((unsigned)nwg), dim3(256), 0, st, a);
