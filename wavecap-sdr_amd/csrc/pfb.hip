@@ -1384,13 +1384,15 @@ static int pfb_run_fmt(wh_pfb *p, const void *d_iq, int fmt, size_t n, float *d_
             a.tw1024 = p->d_tw;
             a.first_hop = 8;
             a.n_groups = n_groups;
-            // Run length.  Three-workgroups form (default): runs of 32 hops (48 for int16 input), neighbouring runs walked in
+            // Run length.  Three-workgroups form (default): runs of 20 hops (32 for int16 input; 31-round sweeps: complex64
+            // 1.186 / 1.195 / 1.211 / 1.223 / 1.281 ms at 16 / 20 / 24 / 32 / 48 hops, int16 1.021 / 1.020 / 1.010 / 1.037 / 1.067 at
+            // 20 / 28 / 32 / 40 / 48), neighbouring runs walked in
             // opposite directions -- the resident workgroups of the chip then sweep one narrow band of addresses, which the
             // HBM channels serve better than 768 scattered streams, and the 9-block halo of a run is an L2 hit (FETCH_SIZE
             // 1.08 x the input at 32 hops; 1.28 x when every run walks upwards).  Two-workgroups forms: runs of
             // 256 hops (halo 3 %).  Either way at least two rounds of resident workgroups when the input allows.
             const bool w3 = p->variant == 0 || p->variant == 5 || p->variant == 7;
-            int gpw = w3 ? (fmt == 1 ? 12 : 8) : 64;
+            int gpw = w3 ? (fmt == 1 ? 8 : 5) : 64;
             long long nwg = (n_groups + gpw - 1) / gpw;
             while (gpw > 2 && nwg < (long long)p->cu_count * (w3 ? 6 : 8)) {
                 gpw = w3 ? gpw - 1 : gpw >> 1;

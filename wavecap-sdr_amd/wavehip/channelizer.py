@@ -120,7 +120,7 @@ class PolyphaseChannelizer:
             _lib.check(_lib.lib.wh_pfb_tune(self._h, self.TUNE_KEYS[k], int(v)), "wh_pfb_tune")
         return self
 
-    def plan(self, samples, out=None, candidates=None, rounds: int = 4) -> int:
+    def plan(self, samples, out=None, candidates=None, rounds: int = 8) -> int:
         """Measure-and-pick planning for calls of this size, on THIS device (the FFTW-planner idea): how many hops a
         workgroup walks decides how the launch's read and write streams meet the HBM channels, and the best length
         differs between otherwise identical MI355X boxes by more than any kernel change of rounds 2-3 moved the time
@@ -133,7 +133,7 @@ class PolyphaseChannelizer:
 
         M1024 = self.channel_count == 1024 and self.taps_per_channel == 9
         if candidates is None:      # 1024 channels: groups of 4 hops per workgroup; shaped kernels: hops per run
-            candidates = (0, 4, 5, 6, 8, 12, 16, 64) if M1024 else (0, 16, 32, 64, 128)
+            candidates = (0, 3, 4, 5, 6, 8, 12, 64) if M1024 else (0, 16, 32, 64, 128)
         hist = self.arm_history
         times: dict[int, list[float]] = {c: [] for c in candidates}
         self.profile(True)
