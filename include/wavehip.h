@@ -386,6 +386,9 @@ int wh_lsm_bank_create(wh_lsm_bank **out, int n_channels, double samples_per_sym
                        const float *h_mmse, int max_samples_per_call);
 int wh_lsm_bank_run(wh_lsm_bank *b, const float *d_iq, size_t n, size_t iq_stride, uint8_t *d_dibits, float *d_phases,
                     size_t cap, int32_t *d_counts, void *stream);
+/* grow the per-call work buffer so that calls of up to n_max samples are accepted (decoders/p25.py:413 takes any length);
+ * carried state is untouched; synchronises the stream; no-op when n_max is not larger than what the bank already takes */
+int wh_lsm_bank_reserve(wh_lsm_bank *b, int n_max, void *stream);
 int wh_lsm_bank_reset(wh_lsm_bank *b, void *stream);
 int wh_lsm_bank_get_state(wh_lsm_bank *b, int channel, double *h_out, void *stream);
 void wh_lsm_bank_destroy(wh_lsm_bank *b);

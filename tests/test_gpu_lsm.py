@@ -125,5 +125,14 @@ def test_lsm_edges():
     a = d.demodulate(inter)
     d2 = wavehip.LSMDemodulator(48000, 4800)
     assert np.array_equal(a, d2.demodulate(x))
-    with pytest.raises(ValueError):
-        wavehip.LSMBank(2, 48000, 4800, max_samples_per_call=128).demodulate(np.zeros((2, 129), np.complex64))
+    # a call longer than the bank was created for grows the work buffers (the reference takes any length and is not
+    # cut-invariant, so the call is never split) and keeps the carried state: same dibits, phases and state as a bank
+    # created large enough, on a stream of three calls of which the second outgrows the small bank twice over
+    xs = np.stack([S.dqpsk_iq(9000, 48000, 1960 + c, symbol_rate=4800, snr_db=14.0)[0] for c in range(2)])
+    small = wavehip.LSMBank(2, 48000, 4800, max_samples_per_call=128)
+    big = wavehip.LSMBank(2, 48000, 4800, max_samples_per_call=16384)
+    for lo, hi in ((0, 100), (100, 5000), (5000, 9000)):
+        (da, pa), (db, pb) = small.demodulate(xs[:, lo:hi], want_phases=True), big.demodulate(xs[:, lo:hi], want_phases=True)
+        for c in range(2):
+            assert np.array_equal(da[c], db[c]) and pa[c].tobytes() == pb[c].tobytes(), (lo, c)
+    assert small.state(1) == big.state(1) and small.max_samples_per_call >= 4900

@@ -452,6 +452,21 @@ extern "C" void wh_lsm_bank_destroy(wh_lsm_bank *b) {
     delete b;
 }
 
+// The reference's demodulate(iq) takes a call of any length (decoders/p25.py:413); only the per-call work buffer of the
+// low-passed samples depends on the call size -- the carried state (AGC, loops, filter history) does not -- so a longer call
+// than the bank was created for grows that buffer and nothing else.  Synchronises the stream (a steady caller never grows).
+extern "C" int wh_lsm_bank_reserve(wh_lsm_bank *b, int n_max, void *stream) {
+    if (!b || n_max < 1) return set_err(WH_E_ARG, "wh_lsm_bank_reserve: bad arguments");
+    if (n_max <= b->n_max) return WH_OK;
+    WH_HIP(hipStreamSynchronize(as_stream(stream)));
+    float2 *nf = nullptr;
+    WH_HIP(hipMalloc(&nf, (size_t)b->C * (NT + (size_t)n_max) * sizeof(float2)));
+    (void)hipFree(b->d_filt);
+    b->d_filt = nf;
+    b->n_max = n_max;
+    return WH_OK;
+}
+
 extern "C" int wh_lsm_bank_reset(wh_lsm_bank *b, void *stream) {
     if (!b) return set_err(WH_E_ARG, "wh_lsm_bank_reset: null handle");
     return lsm_reset(b, as_stream(stream));

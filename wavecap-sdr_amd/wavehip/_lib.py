@@ -154,6 +154,7 @@ PROTOTYPES = {
     "wh_lsm_bank_create": (c_int, [C.POINTER(c_void_p), c_int, c_double, C.POINTER(c_float), C.POINTER(c_float), c_int]),
     "wh_lsm_bank_run": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p, c_size_t, c_void_p,
                                 c_void_p]),
+    "wh_lsm_bank_reserve": (c_int, [c_void_p, c_int, c_void_p]),
     "wh_lsm_bank_reset": (c_int, [c_void_p, c_void_p]),
     "wh_lsm_bank_get_state": (c_int, [c_void_p, c_int, C.POINTER(c_double), c_void_p]),
     "wh_lsm_bank_destroy": (None, [c_void_p]),

@@ -74,6 +74,17 @@ class LSMBank:
     def reset(self) -> None:
         _lib.check(_lib.lib.wh_lsm_bank_reset(self._h, _lib.stream_ptr(self._torch)), "wh_lsm_bank_reset")
 
+    def reserve(self, max_samples_per_call: int) -> None:
+        """Grow the bank for calls of up to `max_samples_per_call` samples per channel (allocates; all demodulator state
+        is kept).  demodulate_device() does it by itself when a longer call arrives."""
+        if max_samples_per_call <= self.max_samples_per_call:
+            return
+        torch = self._torch
+        _lib.check(_lib.lib.wh_lsm_bank_reserve(self._h, int(max_samples_per_call), _lib.stream_ptr(torch)), "wh_lsm_bank_reserve")
+        self.max_samples_per_call = self.cap = int(max_samples_per_call)
+        self._dibits = torch.empty((self.n_channels, self.cap), dtype=torch.uint8, device="cuda")
+        self._phases = None
+
     def state(self, channel: int = 0) -> dict:
         out = (C.c_double * 7)()
         _lib.check(_lib.lib.wh_lsm_bank_get_state(self._h, int(channel), out, _lib.stream_ptr(self._torch)),
@@ -89,7 +100,9 @@ class LSMBank:
         assert iq_dev.shape[0] == self.n_channels and iq_dev.stride(1) == 1
         n = iq_dev.shape[1]
         if n > self.max_samples_per_call:
-            raise ValueError(f"call of {n} samples exceeds max_samples_per_call={self.max_samples_per_call}")
+            # the reference takes a call of any length (decoders/p25.py:413) and is NOT invariant to where a stream is cut
+            # (np.convolve(..., 'same') per call), so a long call is never split: the work buffers grow, state is kept
+            self.reserve(max(n, self.max_samples_per_call + self.max_samples_per_call // 2))
         stride = iq_dev.stride(0) if self.n_channels > 1 else n
         if want_phases and self._phases is None:
             self._phases = torch.empty((self.n_channels, self.cap), dtype=torch.float32, device="cuda")
