@@ -113,6 +113,7 @@ static float np_pairwise_f32(const float *a, size_t n) {
 }
 
 static float mean_mag(const lsm_ref *h, const float *iq, int n) {
+    if (n <= 0) return 0.0f; /* (callers never pass an empty block: demodulate() returns before the AGC) */
     if (h->flavour == 0) {
         float *m = (float *)malloc(sizeof(float) * (size_t)n);
         for (int i = 0; i < n; ++i) m[i] = hypotf(iq[2 * i], iq[2 * i + 1]);
